@@ -1,0 +1,198 @@
+/*
+ * rt_amd.h - C ABI of the MI355X (gfx950) per-pixel render loop.
+ *
+ * This is the drop-in boundary for the reference renderer's hot path.  The
+ * reference (LewisBray/RayTracer) has no FFI: its whole program is one
+ * translation unit of static functions (Source/main.cpp:18-23).  The entry
+ * points below are what a maintainer would bind in place of
+ *   - the per-row driver   render_scanline(...)      Source/render_work_queue.h:28-36
+ *   - the work queue       thread_proc / push_entry  Source/render_work_queue.cpp:3-13,59-80
+ *   - the tracing kernel   intersect(Ray,Scene,int)  Source/ray_tracing.h:137
+ *   - primary rays         ray_direction_through_pixel  Source/ray_tracing.h:127-135
+ *   - the AABB cull        intersect(Ray,AABB)       Source/ray_tracing.h:51
+ * and, for the front end that feeds them,
+ *   - parse_input_file(const char*)                  Source/input_parsing.h:20
+ *   - the camera set-up in main()                    Source/main.cpp:44-57
+ *
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ * All functions return 0 on success and a non-zero code on failure, in which
+ * case rt_last_error() returns a static / thread-local message (the reference
+ * reports errors the same way: a `const char* error`, Source/input_parsing.h:15-18).
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- scene data: exactly the reference's in-memory layout ------------------
+ * Every pointer addresses host memory laid out like the matching std::vector
+ * in the reference's `Scene` (Source/ray_tracing.h:88-106), so a binding passes
+ * `scene.triangle8s.data()` etc. unchanged:
+ *   Triangle8  = 9 x float[8]  (a.x a.y a.z a_to_b.x .. a_to_c.z), 288 B   ray_tracing.h:18-22
+ *   Sphere8    = 4 x float[8]  (centre.x centre.y centre.z radius), 128 B   ray_tracing.h:24-27
+ *   Mat3x4x8   = float[3][4][8], 384 B                                     ray_tracing.h:14-16
+ *   Material   = 10 floats (diffuse rgb, specular rgb, emission rgb, shininess), 40 B  ray_tracing.h:72-77
+ *   PointLightSource = 6 floats (position xyz, colour rgb)                 ray_tracing.h:67-70
+ * The last batch of 8 is zero padded, as the reference's parser leaves it
+ * (Source/input_parsing.cpp:260-262,354-357,418-420).
+ */
+typedef struct rt_scene_desc {
+    const float* triangle8s;                    /* n_triangle8 * 72 floats */
+    const float* triangle_materials;            /* n_triangles * 10 floats */
+    const float* sphere8s;                      /* n_sphere8 * 32 floats */
+    const float* sphere_materials;              /* n_spheres * 10 floats */
+    const float* ellipsoid8_inverse_transforms; /* n_ellipsoid8 * 96 floats */
+    const float* ellipsoid8_transforms;         /* n_ellipsoid8 * 96 floats */
+    const float* ellipsoid_materials;           /* n_ellipsoids * 10 floats */
+    const float* point_light_sources;           /* n_point_lights * 6 floats */
+    uint64_t n_triangle8;
+    uint64_t n_triangles;
+    uint64_t n_sphere8;
+    uint64_t n_spheres;
+    uint64_t n_ellipsoid8;
+    uint64_t n_ellipsoids;
+    uint64_t n_point_lights;
+    float bounding_box[6];        /* min_x max_x min_y max_y min_z max_z  (maths.h:55-62) */
+    float ambient[3];
+    float attenuation[3];         /* constant, linear, quadratic (ray_tracing.h:79-83) */
+    float directional_light[6];   /* unit direction xyz, colour rgb (ray_tracing.h:62-65) */
+    int32_t has_directional_light;
+    int32_t reserved_;
+} rt_scene_desc;
+
+/* Camera as render_scanline receives it: the eye, the basis main() derives
+ * (Source/main.cpp:44-52) and tan(fov/2) per axis (Source/main.cpp:54-57). */
+typedef struct rt_camera_desc {
+    float eye[3];
+    float basis_i[3];
+    float basis_j[3];
+    float basis_k[3];
+    float half_world[2];          /* width, height */
+} rt_camera_desc;
+
+/* What to render.  width/height are the full image (they define the rays);
+ * the rectangle [rect_x0, rect_x0+rect_w) x [rect_y0, rect_y0+rect_h) is the
+ * part that is traced and returned (rect_w == 0 means the whole image).
+ * The rectangle is cut into 16x16-pixel tiles in row-major order; the call
+ * renders tiles t with  t % tile_world == tile_rank  (tile_world == 0 or 1:
+ * all of them).  This replaces the scanline queue of
+ * Source/render_work_queue.cpp:59-80. */
+typedef struct rt_render_params {
+    uint32_t width;
+    uint32_t height;
+    int32_t  max_bounce_count;    /* FileInfo::max_recursion_depth */
+    uint32_t rect_x0, rect_y0, rect_w, rect_h;
+    uint32_t tile_rank, tile_world;
+    uint32_t chunk_tiles;         /* tiles traced per batch of launches; 0 = default */
+    uint32_t flags;               /* RT_FLAG_* */
+    uint32_t reserved_;
+} rt_render_params;
+
+#define RT_TILE 16u
+#define RT_SAMPLES_PER_PIXEL 16u  /* SQRT_SAMPLES_PER_PIXEL^2, render_work_queue.cpp:24-29 */
+
+#define RT_FLAG_NO_FILTER 1u      /* run every ray-triangle test through the full test; no conservative pre-test */
+
+/* Primary-hit id of one sample, as stored in the id buffer. */
+#define RT_ID_KIND_TRIANGLE  0u
+#define RT_ID_KIND_SPHERE    1u
+#define RT_ID_KIND_ELLIPSOID 2u
+#define RT_ID_MISS   0xFFFFFFFFu  /* ray entered the scene box and hit nothing */
+#define RT_ID_CULLED 0xFFFFFFFEu  /* rejected by the scene bounding box (render_work_queue.cpp:45-46) */
+#define RT_ID_MAKE(kind, index) (((uint32_t)(kind) << 30) | (uint32_t)(index))
+
+/* Exact work counters of one render call. */
+typedef struct rt_stats {
+    uint64_t samples;             /* samples generated */
+    uint64_t culled;              /* rejected by the bounding box */
+    uint64_t closest_rays;        /* ray segments scanned for the closest hit (all bounces) */
+    uint64_t hits;                /* of which hit something */
+    uint64_t shadow_rays;         /* shadow ray segments */
+    uint64_t shadow_blocked;      /* of which blocked */
+    uint64_t closest_tests[3];    /* ray-primitive tests, closest hit: triangle, sphere, ellipsoid (unpadded counts) */
+    uint64_t shadow_tests[3];     /* ray-primitive tests, shadow rays, up to the point the ray's wave stopped scanning */
+    double   device_ms;           /* HIP-event time of all launches of this call */
+    double   scan_ms;             /* HIP-event time spent in the closest-hit + shadow scan kernels only */
+    uint64_t scan_launches;       /* number of scan-kernel launches timed in scan_ms */
+    uint64_t full_tests;          /* ray-triangle tests that went through the full test after the pre-test (0 with RT_FLAG_NO_FILTER) */
+} rt_stats;
+
+typedef struct rt_scene rt_scene;          /* opaque: device-resident scene */
+typedef struct rt_file_info rt_file_info;  /* opaque: a parsed .test file */
+
+/* ---- library ---------------------------------------------------------------*/
+/* Select the HIP device this process renders on and create its stream. */
+int rt_init(int device);
+/* Message of the last failing call on this thread. */
+const char* rt_last_error(void);
+/* Number of HIP devices visible, or -1. */
+int rt_device_count(void);
+
+/* ---- scene upload (replaces nothing in the reference: it is the H2D step) ---*/
+int rt_scene_create(const rt_scene_desc* desc, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+
+/* ---- the render loop ---------------------------------------------------------
+ * rt_render: replacement for the loop `for y: render_scanline(...)` driven by
+ * thread_proc (Source/render_work_queue.cpp:15-80).  rgb_out (host) receives
+ * rect_h rows of rect_w RGB8 pixels, row 0 on top, as Image::pixels does
+ * (render_work_queue.cpp:52-55).  primary_id_out (host, nullable) receives
+ * rect_w*rect_h*16 ids, index (y*rect_w + x)*16 + sample.
+ * With tile_world > 1 only this rank's tiles are written; other pixels are left untouched. */
+int rt_render(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params,
+              uint8_t* rgb_out, uint32_t* primary_id_out, rt_stats* stats);
+
+/* Same, but the result stays in device memory as a compact tile buffer:
+ * tile s of this rank (global tile t = s*tile_world + tile_rank) occupies bytes
+ * [s*768, (s+1)*768) as 16 rows of 16 RGB8 pixels.  tiles_dev must hold
+ * rt_rank_tile_count(params) * 768 bytes.  Used by the multi-GPU path, whose
+ * RCCL gather consumes device buffers, and by the benchmark. */
+int rt_render_tiles_device(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params,
+                           void* tiles_dev, rt_stats* stats);
+/* Number of tiles rank `tile_rank` of `tile_world` renders for these params. */
+uint32_t rt_rank_tile_count(const rt_render_params* params);
+/* Total tiles of the rectangle. */
+uint32_t rt_total_tile_count(const rt_render_params* params);
+/* Scatter gathered tile buffers (rank-major: rank r's buffer at offset
+ * r * tiles_per_rank_stride * 768 bytes) into a row-major rect_w x rect_h RGB8
+ * image.  Both pointers are device memory. */
+int rt_assemble_tiles_device(const void* gathered_tiles_dev, uint32_t tiles_per_rank_stride,
+                             const rt_render_params* params, void* rgb_dev);
+
+/* ---- front end (host) --------------------------------------------------------*/
+/* parse_input_file (Source/input_parsing.cpp:96-603).  On a parse error returns
+ * non-zero and rt_last_error() is the reference's message for that error. */
+int rt_parse_input_file(const char* filename, rt_file_info** out);
+void rt_file_info_destroy(rt_file_info* info);
+/* Views into the parsed FileInfo (Source/input_parsing.h:8-13); valid until destroy. */
+const rt_scene_desc* rt_file_info_scene(const rt_file_info* info);
+uint32_t rt_file_info_width(const rt_file_info* info);
+uint32_t rt_file_info_height(const rt_file_info* info);
+int32_t rt_file_info_max_recursion_depth(const rt_file_info* info);
+const char* rt_file_info_output_filename(const rt_file_info* info);
+/* camera[11] = eye xyz, look_at xyz, up xyz, field_of_view x, y (ray_tracing.h:29-39) */
+void rt_file_info_camera(const rt_file_info* info, float camera[11]);
+/* Override the image size after parsing, recomputing field_of_view.x the way the
+ * `camera` command does (Source/input_parsing.cpp:215-216). */
+void rt_file_info_set_size(rt_file_info* info, uint32_t width, uint32_t height);
+
+/* Camera basis and half image extents, main.cpp:44-57. camera11 as above. */
+void rt_camera_setup(const float camera11[11], rt_camera_desc* out);
+
+/* Whole reference flow for one file: parse, set up the camera, upload, render
+ * (Source/main.cpp:33-91).  rgb_out holds width*height*3 bytes. */
+int rt_render_file_info(const rt_file_info* info, uint8_t* rgb_out, rt_stats* stats);
+
+/* Write an RGB8 image as PNG (stands where main.cpp:93 calls stbi_write_png;
+ * pixel-identical, not byte-identical). */
+int rt_write_png(const char* filename, uint32_t width, uint32_t height, const uint8_t* rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */
