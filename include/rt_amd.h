@@ -117,8 +117,10 @@ typedef struct rt_stats {
     uint64_t closest_tests[3];    /* ray-primitive tests, closest hit: triangle, sphere, ellipsoid (unpadded counts) */
     uint64_t shadow_tests[3];     /* ray-primitive tests, shadow rays, up to the point the ray's wave stopped scanning */
     double   device_ms;           /* HIP-event time of all launches of this call */
-    double   scan_ms;             /* HIP-event time spent in the closest-hit + shadow scan kernels only */
-    uint64_t scan_launches;       /* number of scan-kernel launches timed in scan_ms */
+    double   closest_ms;          /* HIP-event time summed over the closest-hit scan launches */
+    double   shadow_ms;           /* HIP-event time summed over the shadow scan launches */
+    uint64_t closest_launches;    /* launches timed in closest_ms */
+    uint64_t shadow_launches;     /* launches timed in shadow_ms */
     uint64_t full_tests;          /* ray-triangle tests that went through the full test after the pre-test (0 with RT_FLAG_NO_FILTER) */
 } rt_stats;
 

@@ -70,8 +70,10 @@ class Stats(C.Structure):
         ("closest_tests", C.c_uint64 * 3),
         ("shadow_tests", C.c_uint64 * 3),
         ("device_ms", C.c_double),
-        ("scan_ms", C.c_double),
-        ("scan_launches", C.c_uint64),
+        ("closest_ms", C.c_double),
+        ("shadow_ms", C.c_double),
+        ("closest_launches", C.c_uint64),
+        ("shadow_launches", C.c_uint64),
         ("full_tests", C.c_uint64),
     ]
 

@@ -1,0 +1,157 @@
+"""Thin Python binding of librt_amd.so (include/rt_amd.h) for the tests and the benchmark.
+
+It mirrors the reference's flow - parse_input_file -> camera set-up -> render -> image
+(Source/main.cpp:33-93) - and adds nothing of its own: every function here is one call
+through the C ABI.  There is no CPU fallback; a missing library or GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librt_amd.so")
+_lib = None
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def lib():
+    """The C-ABI library, loaded once.  Raises if it was not built (see __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RtError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C raytracer_amd/csrc`" % LIB_PATH)
+        _lib = abi.bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtError(lib().rt_last_error().decode("utf-8", "replace"))
+
+
+def init(device=0):
+    _check(lib().rt_init(int(device)))
+
+
+class FileInfo:
+    """A parsed `.test` file: the reference's FileInfo (Source/input_parsing.h:8-13)."""
+
+    def __init__(self, filename):
+        h = C.c_void_p()
+        _check(lib().rt_parse_input_file(os.fsencode(filename), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().rt_file_info_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def scene_desc(self):
+        return lib().rt_file_info_scene(self._h).contents
+
+    @property
+    def width(self):
+        return lib().rt_file_info_width(self._h)
+
+    @property
+    def height(self):
+        return lib().rt_file_info_height(self._h)
+
+    @property
+    def max_recursion_depth(self):
+        return lib().rt_file_info_max_recursion_depth(self._h)
+
+    @property
+    def output_filename(self):
+        return lib().rt_file_info_output_filename(self._h).decode()
+
+    @property
+    def camera11(self):
+        cam = (C.c_float * 11)()
+        lib().rt_file_info_camera(self._h, C.byref(cam))
+        return cam
+
+    def set_size(self, width, height):
+        lib().rt_file_info_set_size(self._h, width, height)
+
+    def camera(self):
+        """Camera basis and half extents as main() computes them (Source/main.cpp:44-57)."""
+        out = abi.CameraDesc()
+        cam = self.camera11
+        lib().rt_camera_setup(C.byref(cam), C.byref(out))
+        return out
+
+    def params(self, **overrides):
+        p = abi.RenderParams(width=self.width, height=self.height, max_bounce_count=self.max_recursion_depth)
+        for k, v in overrides.items():
+            setattr(p, k, v)
+        return p
+
+
+class Scene:
+    """Device-resident scene (rt_scene)."""
+
+    def __init__(self, desc):
+        h = C.c_void_p()
+        _check(lib().rt_scene_create(C.byref(desc), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().rt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, camera, params, want_ids=False):
+        """rt_render: returns dict(rgb[h,w,3] uint8, ids[h,w,16] uint32 or None, stats)."""
+        rw = params.rect_w or params.width
+        rh = params.rect_h if params.rect_w else params.height
+        rgb = np.zeros((rh, rw, 3), np.uint8)
+        ids = np.zeros((rh, rw, 16), np.uint32) if want_ids else None
+        stats = abi.Stats()
+        _check(lib().rt_render(self._h, C.byref(camera), C.byref(params), rgb.ctypes.data,
+                               ids.ctypes.data if want_ids else None, C.byref(stats)))
+        return {"rgb": rgb, "ids": ids, "stats": stats}
+
+    def render_tiles_device(self, camera, params, tiles_dev_ptr, want_stats=True):
+        """rt_render_tiles_device into caller-owned device memory (an integer address)."""
+        stats = abi.Stats()
+        _check(lib().rt_render_tiles_device(self._h, C.byref(camera), C.byref(params), C.c_void_p(tiles_dev_ptr),
+                                            C.byref(stats) if want_stats else None))
+        return stats
+
+
+def rank_tile_count(params):
+    return lib().rt_rank_tile_count(C.byref(params))
+
+
+def total_tile_count(params):
+    return lib().rt_total_tile_count(C.byref(params))
+
+
+def assemble_tiles_device(gathered_ptr, tiles_per_rank_stride, params, rgb_ptr):
+    _check(lib().rt_assemble_tiles_device(C.c_void_p(gathered_ptr), tiles_per_rank_stride, C.byref(params), C.c_void_p(rgb_ptr)))
+
+
+def write_png(filename, rgb):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    _check(lib().rt_write_png(os.fsencode(filename), rgb.shape[1], rgb.shape[0], rgb.ctypes.data))

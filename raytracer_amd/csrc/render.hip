@@ -1,0 +1,1172 @@
+// gfx950 (MI355X) implementation of the reference renderer's per-pixel loop, and the
+// C ABI around it (include/rt_amd.h).
+//
+// One image is traced as a stream of ray batches instead of one recursive call per sample:
+//   k_primary  : camera rays + scene-box cull            (ray_tracing.cpp:460-473, :265-297, render_work_queue.cpp:37-49)
+//   k_closest  : brute-force closest hit over every primitive, kind choice, normal,
+//                ambient + emission                       (ray_tracing.cpp:484-686)
+//   k_shadow   : brute-force any-hit toward one light     (ray_tracing.cpp:347-458)
+//   k_shade    : Blinn-Phong per unblocked light, attenuation, reflection (ray_tracing.cpp:687-728)
+//   k_resolve  : 16-sample average and 8-bit conversion   (render_work_queue.cpp:51-55)
+// Rays that are still alive are kept in compacted index lists, so the two scan kernels,
+// where all the time goes, always run with full wavefronts.  In the scan kernels a lane
+// owns RAYS_PER_LANE rays, a workgroup walks the primitive list in tiles staged in LDS,
+// and every lane reads the same primitive record (an LDS broadcast).
+//
+// Arithmetic contract: IEEE binary32, round to nearest, denormals kept, no contraction
+// (-ffp-contract=off); the fused multiply-adds the reference executes are explicit
+// __builtin_fmaf calls, in the reference's operand order.  Division and square root are
+// the correctly rounded ones (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_internal.h"
+
+// ------------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error = "";
+
+int rt_fail(int code, const char* message) {
+    g_last_error = message ? message : "";
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            char buf_[512];                                                                   \
+            std::snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return rt_fail(RT_ERR_DEVICE, buf_);                                              \
+        }                                                                                     \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// device-side data
+// ------------------------------------------------------------------------------------------
+namespace {
+
+constexpr float TOL = 1.0e-4f;            // maths.h:10
+constexpr int BLOCK = 256;                // threads per workgroup in every kernel
+constexpr int TILE_PRIMS = 256;           // primitives staged in LDS per step (triangles: 64 B each)
+constexpr uint32_t SAMPLES_PER_TILE = RT_TILE * RT_TILE * RT_SAMPLES_PER_PIXEL;  // 4096
+
+// Primitive lists are stored in "scan order": entry k holds the primitive the reference
+// keeps in lane j = k / nb of batch i = k % nb (original index 8*i + j).  Walking k upward
+// with a strict `<` then yields the reference's winner among equal distances, which is the
+// smallest (distance, lane, batch), not the smallest index (ray_tracing.cpp:489-516).
+struct DevScene {
+    const float4* tri;   // 4 x float4 per triangle: (a, n.x) (a_to_b, n.y) (a_to_c, n.z) (n.n, 0, 0, 0)
+    const float4* sph;   // (centre, radius)
+    const float4* ell;   // 6 x float4: rows of the inverse transform, rows of the transform
+    const float4* ell_light;  // [point light][ellipsoid]: inverse transform applied to the light position
+    const float* tri_mat;
+    const float* sph_mat;
+    const float* ell_mat;
+    const float* lights;  // 8 floats per light: kind (0 directional, 1 point), xyz, rgb, 0; directional first
+    uint32_t n_tri, tri_nb;   // scan entries (8 * batches), batches
+    uint32_t n_sph, sph_nb;
+    uint32_t n_ell, ell_nb;
+    uint32_t n_tri_mat, n_sph_mat, n_ell_mat;
+    uint32_t n_lights, has_directional;
+    float bb[6];
+    float ambient[3];
+    float atten[3];
+};
+
+struct Frame {
+    float eye[3], bi[3], bj[3], bk[3], hw[2];
+    float half_w_px, half_h_px;
+    uint32_t rect_x0, rect_y0, rect_w, rect_h;
+    uint32_t tiles_x;
+    uint32_t tile_rank, tile_world;
+};
+
+// Per-sample state of one chunk, structure of arrays, indexed by the sample's slot.
+struct State {
+    float *ox, *oy, *oz, *dx, *dy, *dz;   // current ray
+    float *wr, *wg, *wb;                  // colour weighting
+    float *cr, *cg, *cb;                  // accumulated colour
+    float *px, *py, *pz, *nx, *ny, *nz;   // hit point and unit normal of the current bounce
+    uint32_t* hit_id;                     // RT_ID_MAKE(kind, original index) of the current bounce
+    uint32_t* blocked;                    // bit l: light l of the current group is blocked
+    uint32_t* list[2];                    // compacted slots of live rays, ping-pong
+    uint32_t* counts;                     // counts[b]: live rays entering bounce b
+    uint32_t* primary_id;                 // nullable
+    unsigned long long* stats;            // ST_* counters
+};
+
+enum { ST_SAMPLES, ST_CULLED, ST_CLOSEST_RAYS, ST_HITS, ST_SHADOW_RAYS, ST_SHADOW_BLOCKED,
+       ST_SHADOW_TESTS_TRI, ST_SHADOW_TESTS_SPH, ST_SHADOW_TESTS_ELL, ST_FULL_TESTS, ST_COUNT };
+
+struct V3 { float x, y, z; };
+
+// ------------------------------------------------------------------------------------------
+// arithmetic building blocks
+// ------------------------------------------------------------------------------------------
+#define DEV __device__ __forceinline__
+
+DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+DEV float fp_min(float x, float y) { return x < y ? x : y; }   // minss: second operand on NaN (maths.cpp:147-152)
+DEV float fp_max(float x, float y) { return x > y ? x : y; }   // maxss (maths.cpp:154-159)
+DEV float sqrt_(float x) { return __builtin_sqrtf(x); }
+
+DEV V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+DEV V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+DEV V3 scale(float s, V3 v) { return {s * v.x, s * v.y, s * v.z}; }
+// scalar Vector dot as clang contracts it: fma(z, z', fma(x, x', y*y'))  (maths.cpp:195-197)
+DEV float sdot(V3 a, V3 b) { return fma_(a.z, b.z, fma_(a.x, b.x, a.y * b.y)); }
+// scalar cross: fma(l.y, r.z, -(l.z*r.y))  (maths.cpp:203-209)
+DEV V3 scross(V3 l, V3 r) { return {fma_(l.y, r.z, -(l.z * r.y)), fma_(l.z, r.x, -(l.x * r.z)), fma_(l.x, r.y, -(l.y * r.x))}; }
+DEV V3 divide(V3 v, float s) { const float inv = 1.0f / s; return {inv * v.x, inv * v.y, inv * v.z}; }
+DEV V3 normalise(V3 v) { return divide(v, sqrt_(sdot(v, v))); }
+// AVX dot: mul, fmadd, fmadd in x, y, z order (ray_tracing.cpp:68-74)
+DEV float vdot(V3 a, V3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+// AVX cross: unfused (ray_tracing.cpp:76-83)
+DEV V3 vcross(V3 l, V3 r) { return {l.y * r.z - l.z * r.y, l.z * r.x - l.x * r.z, l.x * r.y - l.y * r.x}; }
+DEV V3 xyz(float4 v) { return {v.x, v.y, v.z}; }
+
+// rows as float4 (m0, m1, m2, m3); AVX forms of ray_tracing.cpp:105-126 and :208-227
+DEV V3 vmat_point(float4 r0, float4 r1, float4 r2, V3 v) {
+    return {r0.w + fma_(r0.z, v.z, fma_(r0.y, v.y, r0.x * v.x)),
+            r1.w + fma_(r1.z, v.z, fma_(r1.y, v.y, r1.x * v.x)),
+            r2.w + fma_(r2.z, v.z, fma_(r2.y, v.y, r2.x * v.x))};
+}
+DEV V3 vmat_dir(float4 r0, float4 r1, float4 r2, V3 v) {
+    return {fma_(r0.z, v.z, fma_(r0.y, v.y, r0.x * v.x)),
+            fma_(r1.z, v.z, fma_(r1.y, v.y, r1.x * v.x)),
+            fma_(r2.z, v.z, fma_(r2.y, v.y, r2.x * v.x))};
+}
+// scalar Matrix*Vector: fma(m2, z, fma(m0, x, m1*y)) + m3 (maths.cpp:226-232)
+DEV V3 smat_point(float4 r0, float4 r1, float4 r2, V3 v) {
+    return {fma_(r0.z, v.z, fma_(r0.x, v.x, r0.y * v.y)) + r0.w,
+            fma_(r1.z, v.z, fma_(r1.x, v.x, r1.y * v.y)) + r1.w,
+            fma_(r2.z, v.z, fma_(r2.x, v.x, r2.y * v.y)) + r2.w};
+}
+// maths.cpp:312-318
+DEV V3 smat_transpose_dir(float4 r0, float4 r1, float4 r2, V3 v) {
+    return {fma_(r2.x, v.z, fma_(r0.x, v.x, r1.x * v.y)),
+            fma_(r2.y, v.z, fma_(r0.y, v.x, r1.y * v.y)),
+            fma_(r2.z, v.z, fma_(r0.z, v.x, r1.z * v.y))};
+}
+
+// fp_pow and its helpers (maths.cpp:9-139)
+DEV int exponent_127(float x) { return static_cast<int>((__float_as_uint(x) >> 23) & 0xFFu); }
+DEV float fp_log2(float x) {
+    const int exponent = exponent_127(x) - 127;
+    const float m = __uint_as_float((__float_as_uint(x) & 0x007FFFFFu) | 0x3F800000u);
+    float acc = 0.0f, mult = 1.0f;
+    acc = fma_(-2.80036404536401f, mult, acc); mult *= m;
+    acc = fma_(5.0917108473873602f, mult, acc); mult *= m;
+    acc = fma_(-3.5507929732452235f, mult, acc); mult *= m;
+    acc = fma_(1.6311487949127739f, mult, acc); mult *= m;
+    acc = fma_(-0.41656369634969576f, mult, acc); mult *= m;
+    acc = fma_(0.044873611393688138f, mult, acc);
+    const float result = acc + static_cast<float>(exponent);
+    return fp_min(result, 0.0f);
+}
+DEV float fp_exp2(float x) {
+    const float clamped = fp_max(x, -127.0f);
+    const float ax = __uint_as_float(__float_as_uint(clamped) & 0x7FFFFFFFu);
+    const int ip = static_cast<int>(ax);
+    const float frac = ax - static_cast<float>(ip);
+    const float inv_int = __uint_as_float((static_cast<uint32_t>(127 - ip) & 0xFFu) << 23);
+    float acc = 0.0f, mult = 1.0f;
+    acc = fma_(0.99994648282537313f, mult, acc); mult *= frac;
+    acc = fma_(-0.69137342261578116f, mult, acc); mult *= frac;
+    acc = fma_(0.23097554273105286f, mult, acc); mult *= frac;
+    acc = fma_(-0.039602120115271706f, mult, acc);
+    return inv_int * acc;
+}
+DEV float fp_pow(float x, float y) {
+    if (exponent_127(y) == 0) return 1.0f;
+    if (exponent_127(x) == 0) return 0.0f;
+    return fp_exp2(y * fp_log2(x));
+}
+
+// ------------------------------------------------------------------------------------------
+// ray / primitive tests (one ray, one primitive)
+// ------------------------------------------------------------------------------------------
+// ray_tracing.cpp:129-165 with the ray-independent n = a_to_b x a_to_c and n.n taken from the record
+DEV float hit_triangle(V3 o, V3 d, float4 t0, float4 t1, float4 t2, float nn) {
+    const V3 a = xyz(t0), ab = xyz(t1), ac = xyz(t2);
+    const V3 n{t0.w, t1.w, t2.w};
+    const float dn = vdot(d, n);
+    const bool parallel = __builtin_fabsf(dn) < TOL;
+    const float t = vdot(sub(a, o), n) / dn;
+    const bool behind = t < TOL;
+    const V3 p = add(o, scale(t, d));
+    const V3 ap = sub(p, a);
+    const float alpha = vdot(vcross(ab, ap), n) / nn;
+    const float beta = vdot(vcross(ap, ac), n) / nn;
+    const bool outside = (alpha < 0.0f) | (beta < 0.0f) | (alpha + beta > 1.0f);
+    return (parallel | behind | outside) ? FLT_MAX : t;
+}
+
+// ray_tracing.cpp:169-206; the far root is replaced by the near one at :202 and that is kept
+DEV float hit_sphere(V3 o, V3 d, float4 s) {
+    const V3 oc = sub(xyz(s), o);
+    const float mid = vdot(oc, d);
+    const float oc2 = vdot(oc, oc);
+    const float mid2 = mid * mid;
+    const float perp2 = oc2 - mid2;
+    const float r2 = s.w * s.w;
+    const float disc = r2 - perp2;
+    const bool none = disc < 0.0f;
+    const float h = sqrt_(disc);
+    const float d0 = mid - h;
+    const float d1 = mid + h;
+    const bool inv0 = none | (d0 < TOL);
+    const bool inv1 = none | (d1 < TOL);
+    const float p0 = inv0 ? FLT_MAX : d0;
+    const float p1 = inv1 ? FLT_MAX : d0;
+    return p0 < p1 ? p0 : p1;
+}
+
+// ray_tracing.cpp:229-263
+DEV float hit_unit_sphere(V3 o, V3 d) {
+    const float mid = vdot(scale(-1.0f, o), d);
+    const float oo = vdot(o, o);
+    const float mid2 = mid * mid;
+    const float perp2 = oo - mid2;
+    const float disc = 1.0f - perp2;
+    const bool none = disc < 0.0f;
+    const float h = sqrt_(disc);
+    const float d0 = mid - h;
+    const float d1 = mid + h;
+    const bool inv0 = none | (d0 < TOL);
+    const bool inv1 = none | (d1 < TOL);
+    const float p0 = inv0 ? FLT_MAX : d0;
+    const float p1 = inv1 ? FLT_MAX : d1;
+    return p0 < p1 ? p0 : p1;
+}
+
+// closest-hit body for one ellipsoid, ray_tracing.cpp:555-579
+DEV float hit_ellipsoid(V3 o, V3 d, float4 i0, float4 i1, float4 i2, float4 m0, float4 m1, float4 m2) {
+    const V3 o2 = vmat_point(i0, i1, i2, o);
+    V3 d2 = vmat_dir(i0, i1, i2, d);
+    const bool absent = (d2.x < TOL) & (d2.y < TOL) & (d2.z < TOL);   // ray_tracing.cpp:336-344
+    const float inv_mag = 1.0f / sqrt_(vdot(d2, d2));
+    d2 = scale(inv_mag, d2);
+    const float t2 = hit_unit_sphere(o2, d2);
+    const V3 p2 = add(o2, scale(t2, d2));
+    const V3 p = vmat_point(m0, m1, m2, p2);
+    const V3 op = sub(p, o);
+    const float dist = sqrt_(vdot(op, op));
+    return absent ? FLT_MAX : dist;
+}
+
+// shadow body for one ellipsoid: true when it blocks (ray_tracing.cpp:376-401, :432-454).
+// l2 is the light position in ellipsoid space (point lights only).
+DEV bool ellipsoid_blocks(V3 o, V3 d, float4 i0, float4 i1, float4 i2, bool point, V3 l2) {
+    const V3 o2 = vmat_point(i0, i1, i2, o);
+    V3 d2 = vmat_dir(i0, i1, i2, d);
+    const bool absent = (d2.x < TOL) & (d2.y < TOL) & (d2.z < TOL);
+    const float inv_mag = 1.0f / sqrt_(vdot(d2, d2));
+    d2 = scale(inv_mag, d2);
+    float limit = FLT_MAX;
+    if (point) {
+        const V3 dl = sub(l2, o2);
+        limit = sqrt_(vdot(dl, dl));
+    }
+    float t2 = hit_unit_sphere(o2, d2);
+    t2 = absent ? FLT_MAX : t2;
+    return t2 < limit;
+}
+
+// ------------------------------------------------------------------------------------------
+// workgroup helpers
+// ------------------------------------------------------------------------------------------
+// Order-preserving append of the flagged lanes of a 256-thread workgroup to a global list.
+// Returns this lane's position (only meaningful when flag is set).
+DEV uint32_t block_append(bool flag, uint32_t* counter, uint32_t* lds4 /* >= 5 words */) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long mask = __ballot(flag);
+    const uint32_t before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) lds4[wave] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+        lds4[4] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t offset = lds4[4];
+    for (uint32_t w = 0; w < wave; ++w) offset += lds4[w];
+    return offset + before;
+}
+
+DEV void block_add_stat(unsigned long long* stat, unsigned long long value) {
+    // wave reduction, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) value += __shfl_down(value, off);
+    if ((threadIdx.x & 63u) == 0 && value) atomicAdd(stat, value);
+}
+
+// ------------------------------------------------------------------------------------------
+// scene preparation: reference AoSoA-8 -> scan-ordered records
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_prep_triangles(const float* __restrict__ tri8, uint32_t nb, float4* __restrict__ out) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= 8u * nb) return;
+    const uint32_t j = k / nb, i = k % nb;
+    const float* p = tri8 + static_cast<size_t>(i) * 72 + j;
+    const V3 a{p[0], p[8], p[16]}, ab{p[24], p[32], p[40]}, ac{p[48], p[56], p[64]};
+    const V3 n = vcross(ab, ac);
+    const float nn = vdot(n, n);
+    float4* o = out + static_cast<size_t>(k) * 4;
+    o[0] = make_float4(a.x, a.y, a.z, n.x);
+    o[1] = make_float4(ab.x, ab.y, ab.z, n.y);
+    o[2] = make_float4(ac.x, ac.y, ac.z, n.z);
+    o[3] = make_float4(nn, 0.0f, 0.0f, 0.0f);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_prep_spheres(const float* __restrict__ sph8, uint32_t nb, float4* __restrict__ out) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= 8u * nb) return;
+    const uint32_t j = k / nb, i = k % nb;
+    const float* p = sph8 + static_cast<size_t>(i) * 32 + j;
+    out[k] = make_float4(p[0], p[8], p[16], p[24]);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_prep_ellipsoids(const float* __restrict__ inv8, const float* __restrict__ fwd8, uint32_t nb, float4* __restrict__ out) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= 8u * nb) return;
+    const uint32_t j = k / nb, i = k % nb;
+    const float* pi = inv8 + static_cast<size_t>(i) * 96 + j;
+    const float* pf = fwd8 + static_cast<size_t>(i) * 96 + j;
+    float4* o = out + static_cast<size_t>(k) * 6;
+    for (int row = 0; row < 3; ++row) {
+        o[row] = make_float4(pi[(row * 4 + 0) * 8], pi[(row * 4 + 1) * 8], pi[(row * 4 + 2) * 8], pi[(row * 4 + 3) * 8]);
+        o[3 + row] = make_float4(pf[(row * 4 + 0) * 8], pf[(row * 4 + 1) * 8], pf[(row * 4 + 2) * 8], pf[(row * 4 + 3) * 8]);
+    }
+}
+
+// inverse transform applied to each point light's position (ray_tracing.cpp:388), once per scene
+__global__ void __launch_bounds__(BLOCK) k_prep_ellipsoid_lights(const float4* __restrict__ ell, uint32_t n_ell, const float* __restrict__ point_lights,
+                                                                 uint32_t n_point, float4* __restrict__ out) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n_ell) return;
+    const float4 i0 = ell[static_cast<size_t>(k) * 6], i1 = ell[static_cast<size_t>(k) * 6 + 1], i2 = ell[static_cast<size_t>(k) * 6 + 2];
+    for (uint32_t l = 0; l < n_point; ++l) {
+        const V3 lp{point_lights[l * 6], point_lights[l * 6 + 1], point_lights[l * 6 + 2]};
+        const V3 l2 = vmat_point(i0, i1, i2, lp);
+        out[static_cast<size_t>(l) * n_ell + k] = make_float4(l2.x, l2.y, l2.z, 0.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_primary: one thread per sample of the chunk
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_primary(Frame f, DevScene sc, State st, uint32_t first_tile_slot) {
+    __shared__ uint32_t lds_scan[8];
+    const uint32_t s = blockIdx.x * BLOCK + threadIdx.x;   // the grid covers the chunk's samples exactly
+    const uint32_t tile_slot = first_tile_slot + s / SAMPLES_PER_TILE;
+    const uint32_t tile = tile_slot * f.tile_world + f.tile_rank;
+    const uint32_t in_tile = s % SAMPLES_PER_TILE;
+    const uint32_t pixel = in_tile / RT_SAMPLES_PER_PIXEL, sample = in_tile % RT_SAMPLES_PER_PIXEL;
+    const uint32_t rx = (tile % f.tiles_x) * RT_TILE + pixel % RT_TILE;
+    const uint32_t ry = (tile / f.tiles_x) * RT_TILE + pixel / RT_TILE;
+    const bool inside = rx < f.rect_w && ry < f.rect_h;
+    const uint32_t x = f.rect_x0 + rx, y = f.rect_y0 + ry;
+
+    // render_work_queue.cpp:40-41: offsets 2.0, 2.25, 2.5, 2.75 (exact in binary32)
+    const float xo = static_cast<float>(sample % 4u) * 0.25f + 2.0f;
+    const float yo = static_cast<float>(sample / 4u) * 0.25f + 2.0f;
+    // ray_tracing.cpp:469-472
+    const float alpha = f.hw[0] * (f.half_w_px - (static_cast<float>(x) + xo)) / f.half_w_px;
+    const float beta = f.hw[1] * (f.half_h_px - (static_cast<float>(y) + yo)) / f.half_h_px;
+    const V3 bi{f.bi[0], f.bi[1], f.bi[2]}, bj{f.bj[0], f.bj[1], f.bj[2]}, bk{f.bk[0], f.bk[1], f.bk[2]};
+    const V3 d = normalise(add(add(scale(alpha, bi), scale(beta, bj)), bk));
+    const V3 o{f.eye[0], f.eye[1], f.eye[2]};
+
+    // ray_tracing.cpp:271-294
+    const float ix = 1.0f / d.x;
+    const float x0 = (sc.bb[0] - o.x) * ix, x1 = (sc.bb[1] - o.x) * ix;
+    const float min_x = fp_min(x0, x1), max_x = fp_max(x0, x1);
+    const float iy = 1.0f / d.y;
+    const float y0 = (sc.bb[2] - o.y) * iy, y1 = (sc.bb[3] - o.y) * iy;
+    const float min_y = fp_min(y0, y1), max_y = fp_max(y0, y1);
+    const float iz = 1.0f / d.z;
+    const float z0 = (sc.bb[4] - o.z) * iz, z1 = (sc.bb[5] - o.z) * iz;
+    const float min_z = fp_min(z0, z1), max_z = fp_max(z0, z1);
+    const float min_distance = fp_max(min_z, fp_max(min_y, min_x));
+    const float max_distance = fp_min(max_z, fp_min(max_y, max_x));
+    const bool live = inside && (max_distance >= min_distance);   // render_work_queue.cpp:46
+
+    st.cr[s] = 0.0f; st.cg[s] = 0.0f; st.cb[s] = 0.0f;
+    if (live) {
+        st.ox[s] = o.x; st.oy[s] = o.y; st.oz[s] = o.z;
+        st.dx[s] = d.x; st.dy[s] = d.y; st.dz[s] = d.z;
+        st.wr[s] = 1.0f; st.wg[s] = 1.0f; st.wb[s] = 1.0f;
+    }
+    if (st.primary_id) st.primary_id[s] = live ? RT_ID_MISS : RT_ID_CULLED;
+    const uint32_t pos = block_append(live, &st.counts[0], lds_scan);
+    if (live) st.list[0][pos] = s;
+    block_add_stat(&st.stats[ST_SAMPLES], inside ? 1ull : 0ull);
+    block_add_stat(&st.stats[ST_CULLED], (inside && !live) ? 1ull : 0ull);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_closest: closest hit of every live ray against every primitive, then the per-hit set-up
+// ------------------------------------------------------------------------------------------
+// LDS staging: a tile of `count` records of WORDS float4 each is copied by the whole
+// workgroup; `lds` must hold TILE_PRIMS * WORDS float4.
+template <int WORDS>
+DEV void stage_tile(float4* lds, const float4* __restrict__ src, uint32_t first, uint32_t count) {
+    const uint32_t n4 = count * WORDS;
+    const float4* g = src + static_cast<size_t>(first) * WORDS;
+    for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) lds[i] = g[i];
+}
+
+template <int R>
+__global__ void __launch_bounds__(BLOCK) k_closest(DevScene sc, State st, uint32_t bounce) {
+    __shared__ float4 lds[TILE_PRIMS * 6];
+    __shared__ uint32_t lds_scan[8];
+    const uint32_t n_rays = st.counts[bounce];
+    const uint32_t base = blockIdx.x * (BLOCK * R);
+    if (base >= n_rays) return;
+    const uint32_t* __restrict__ list_in = st.list[bounce & 1u];
+
+    uint32_t slot[R];
+    bool valid[R];
+    V3 o[R], d[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = base + r * BLOCK + threadIdx.x;
+        valid[r] = i < n_rays;
+        slot[r] = list_in[valid[r] ? i : base];
+        o[r] = {st.ox[slot[r]], st.oy[slot[r]], st.oz[slot[r]]};
+        d[r] = {st.dx[slot[r]], st.dy[slot[r]], st.dz[slot[r]]};
+    }
+
+    // ---- triangles ----
+    float tri_t[R]; uint32_t tri_k[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { tri_t[r] = FLT_MAX; tri_k[r] = 0xFFFFFFFFu; }
+    for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
+        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
+        __syncthreads();
+        stage_tile<4>(lds, sc.tri, first, count);
+        __syncthreads();
+#pragma unroll 2
+        for (uint32_t k = 0; k < count; ++k) {
+            const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float t = hit_triangle(o[r], d[r], t0, t1, t2, t3.x);
+                if (t < tri_t[r]) { tri_t[r] = t; tri_k[r] = first + k; }
+            }
+        }
+    }
+    // ---- spheres ----
+    float sph_t[R]; uint32_t sph_k[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { sph_t[r] = FLT_MAX; sph_k[r] = 0xFFFFFFFFu; }
+    for (uint32_t first = 0; first < sc.n_sph; first += TILE_PRIMS) {
+        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_sph - first);
+        __syncthreads();
+        stage_tile<1>(lds, sc.sph, first, count);
+        __syncthreads();
+#pragma unroll 2
+        for (uint32_t k = 0; k < count; ++k) {
+            const float4 s = lds[k];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float t = hit_sphere(o[r], d[r], s);
+                if (t < sph_t[r]) { sph_t[r] = t; sph_k[r] = first + k; }
+            }
+        }
+    }
+    // ---- ellipsoids ----
+    float ell_t[R]; uint32_t ell_k[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { ell_t[r] = FLT_MAX; ell_k[r] = 0xFFFFFFFFu; }
+    for (uint32_t first = 0; first < sc.n_ell; first += TILE_PRIMS) {
+        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_ell - first);
+        __syncthreads();
+        stage_tile<6>(lds, sc.ell, first, count);
+        __syncthreads();
+        for (uint32_t k = 0; k < count; ++k) {
+            const float4 i0 = lds[k * 6], i1 = lds[k * 6 + 1], i2 = lds[k * 6 + 2];
+            const float4 m0 = lds[k * 6 + 3], m1 = lds[k * 6 + 4], m2 = lds[k * 6 + 5];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float t = hit_ellipsoid(o[r], d[r], i0, i1, i2, m0, m1, m2);
+                if (t < ell_t[r]) { ell_t[r] = t; ell_k[r] = first + k; }
+            }
+        }
+    }
+
+    // ---- per-ray epilogue: kind choice, hit point, normal, ambient + emission ----
+    unsigned long long n_valid = 0, n_hit = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t s = slot[r];
+        const bool any = (tri_k[r] != 0xFFFFFFFFu) | (sph_k[r] != 0xFFFFFFFFu) | (ell_k[r] != 0xFFFFFFFFu);
+        // ray_tracing.cpp:616, :637, :655
+        int kind = -1;
+        if (any) {
+            if (tri_t[r] - sph_t[r] <= TOL && tri_t[r] - ell_t[r] <= TOL) kind = 0;
+            else if (sph_t[r] - tri_t[r] <= TOL && sph_t[r] - ell_t[r] <= TOL) kind = 1;
+            else if (ell_t[r] - tri_t[r] <= TOL && ell_t[r] - sph_t[r] <= TOL) kind = 2;
+        }
+        const bool hit = valid[r] && kind >= 0;
+        if (hit) {
+            V3 p, n;
+            uint32_t index;
+            const float* mat;
+            uint32_t mat_count;
+            if (kind == 0) {
+                const uint32_t k = tri_k[r];
+                index = 8u * (k % sc.tri_nb) + k / sc.tri_nb;
+                p = add(o[r], scale(tri_t[r], d[r]));
+                const float4 t0 = sc.tri[static_cast<size_t>(k) * 4], t1 = sc.tri[static_cast<size_t>(k) * 4 + 1], t2 = sc.tri[static_cast<size_t>(k) * 4 + 2];
+                const V3 a = xyz(t0);
+                const V3 vb = add(xyz(t1), a), vc = add(xyz(t2), a);      // ray_tracing.cpp:631-632
+                n = normalise(scross(sub(vb, a), sub(vc, a)));            // maths.cpp:304-306
+                mat = sc.tri_mat; mat_count = sc.n_tri_mat;
+            } else if (kind == 1) {
+                const uint32_t k = sph_k[r];
+                index = 8u * (k % sc.sph_nb) + k / sc.sph_nb;
+                p = add(o[r], scale(sph_t[r], d[r]));
+                n = normalise(sub(p, xyz(sc.sph[k])));                    // maths.cpp:308-310
+                mat = sc.sph_mat; mat_count = sc.n_sph_mat;
+            } else {
+                const uint32_t k = ell_k[r];
+                index = 8u * (k % sc.ell_nb) + k / sc.ell_nb;
+                p = add(o[r], scale(ell_t[r], d[r]));
+                const float4 i0 = sc.ell[static_cast<size_t>(k) * 6], i1 = sc.ell[static_cast<size_t>(k) * 6 + 1], i2 = sc.ell[static_cast<size_t>(k) * 6 + 2];
+                const V3 pe = smat_point(i0, i1, i2, p);                  // maths.cpp:320-326
+                const V3 ne = normalise(pe);
+                n = normalise(smat_transpose_dir(i0, i1, i2, ne));
+                mat = sc.ell_mat; mat_count = sc.n_ell_mat;
+            }
+            // A hit on a zero-padding lane has no material; the reference reads past its vector there.
+            float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
+            if (index < mat_count) { e0 = mat[index * 10 + 6]; e1 = mat[index * 10 + 7]; e2 = mat[index * 10 + 8]; }
+            st.cr[s] += st.wr[s] * (sc.ambient[0] + e0);                   // ray_tracing.cpp:682
+            st.cg[s] += st.wg[s] * (sc.ambient[1] + e1);
+            st.cb[s] += st.wb[s] * (sc.ambient[2] + e2);
+            st.px[s] = p.x; st.py[s] = p.y; st.pz[s] = p.z;
+            st.nx[s] = n.x; st.ny[s] = n.y; st.nz[s] = n.z;
+            const uint32_t id = RT_ID_MAKE(static_cast<uint32_t>(kind), index);
+            st.hit_id[s] = id;
+            st.blocked[s] = 0u;
+            if (bounce == 0 && st.primary_id) st.primary_id[s] = id;
+        }
+        const uint32_t pos = block_append(hit, &st.counts[bounce + 1], lds_scan);
+        if (hit) st.list[(bounce + 1) & 1u][pos] = s;
+        __syncthreads();
+        n_valid += valid[r] ? 1ull : 0ull;
+        n_hit += hit ? 1ull : 0ull;
+    }
+    block_add_stat(&st.stats[ST_CLOSEST_RAYS], n_valid);
+    block_add_stat(&st.stats[ST_HITS], n_hit);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_shadow: any-hit of every hit point toward light (first_light + blockIdx.y)
+// ------------------------------------------------------------------------------------------
+template <int R>
+__global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, State st, uint32_t bounce, uint32_t first_light) {
+    __shared__ float4 lds[TILE_PRIMS * 4];
+    const uint32_t n_rays = st.counts[bounce + 1];
+    const uint32_t base = blockIdx.x * (BLOCK * R);
+    if (base >= n_rays) return;
+    const uint32_t* __restrict__ list_in = st.list[(bounce + 1) & 1u];
+    const uint32_t light = first_light + blockIdx.y;
+    const float* __restrict__ L = sc.lights + light * 8;
+    const bool point = L[0] != 0.0f;
+    const V3 lv{L[1], L[2], L[3]};
+
+    uint32_t slot[R];
+    bool valid[R], blocked[R];
+    V3 o[R], d[R];
+    float limit[R];
+    uint32_t tests[R][3];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = base + r * BLOCK + threadIdx.x;
+        valid[r] = i < n_rays;
+        slot[r] = list_in[valid[r] ? i : base];
+        const V3 p{st.px[slot[r]], st.py[slot[r]], st.pz[slot[r]]};
+        const V3 n{st.nx[slot[r]], st.ny[slot[r]], st.nz[slot[r]]};
+        o[r] = add(p, scale(2.0f * TOL, n));                               // ray_tracing.cpp:685-686
+        if (point) {                                                       // ray_tracing.cpp:350-354
+            const V3 to_light = sub(lv, o[r]);
+            limit[r] = sqrt_(sdot(to_light, to_light));
+            const float inv = 1.0f / limit[r];
+            d[r] = scale(inv, to_light);
+        } else {                                                           // ray_tracing.cpp:410-412
+            d[r] = scale(-1.0f, lv);
+            limit[r] = FLT_MAX;
+        }
+        blocked[r] = false;
+        tests[r][0] = tests[r][1] = tests[r][2] = 0;
+    }
+
+    auto wave_done = [&]() {
+        bool all = true;
+#pragma unroll
+        for (int r = 0; r < R; ++r) all = all && (blocked[r] || !valid[r]);
+        return __all(all) != 0;
+    };
+    bool done = wave_done();
+
+    for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
+        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
+        if (__syncthreads_and(done)) break;
+        stage_tile<4>(lds, sc.tri, first, count);
+        __syncthreads();
+        if (!done) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (valid[r] && !blocked[r]) tests[r][0] += count;
+#pragma unroll 2
+            for (uint32_t k = 0; k < count; ++k) {
+                const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
+#pragma unroll
+                for (int r = 0; r < R; ++r) blocked[r] |= hit_triangle(o[r], d[r], t0, t1, t2, t3.x) < limit[r];
+            }
+            done = wave_done();
+        }
+    }
+    for (uint32_t first = 0; first < sc.n_sph; first += TILE_PRIMS) {
+        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_sph - first);
+        if (__syncthreads_and(done)) break;
+        stage_tile<1>(lds, sc.sph, first, count);
+        __syncthreads();
+        if (!done) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (valid[r] && !blocked[r]) tests[r][1] += count;
+#pragma unroll 2
+            for (uint32_t k = 0; k < count; ++k) {
+                const float4 s = lds[k];
+#pragma unroll
+                for (int r = 0; r < R; ++r) blocked[r] |= hit_sphere(o[r], d[r], s) < limit[r];
+            }
+            done = wave_done();
+        }
+    }
+    const uint32_t point_index = light - sc.has_directional;   // index among the point lights
+    for (uint32_t first = 0; first < sc.n_ell; first += TILE_PRIMS) {
+        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_ell - first);
+        if (__syncthreads_and(done)) break;
+        // three inverse-transform rows, then the light position in ellipsoid space
+        for (uint32_t i = threadIdx.x; i < count * 4; i += BLOCK) {
+            const uint32_t k = i / 4, w = i % 4;
+            lds[i] = (w < 3) ? sc.ell[static_cast<size_t>(first + k) * 6 + w]
+                             : (point ? sc.ell_light[static_cast<size_t>(point_index) * sc.n_ell + first + k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        }
+        __syncthreads();
+        if (!done) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (valid[r] && !blocked[r]) tests[r][2] += count;
+            for (uint32_t k = 0; k < count; ++k) {
+                const float4 i0 = lds[k * 4], i1 = lds[k * 4 + 1], i2 = lds[k * 4 + 2], l2 = lds[k * 4 + 3];
+#pragma unroll
+                for (int r = 0; r < R; ++r) blocked[r] |= ellipsoid_blocks(o[r], d[r], i0, i1, i2, point, xyz(l2));
+            }
+            done = wave_done();
+        }
+    }
+
+    unsigned long long n_valid = 0, n_blocked = 0, t_tri = 0, t_sph = 0, t_ell = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (valid[r]) {
+            n_valid++;
+            if (blocked[r]) { n_blocked++; atomicOr(&st.blocked[slot[r]], 1u << blockIdx.y); }
+            t_tri += tests[r][0]; t_sph += tests[r][1]; t_ell += tests[r][2];
+        }
+    }
+    block_add_stat(&st.stats[ST_SHADOW_RAYS], n_valid);
+    block_add_stat(&st.stats[ST_SHADOW_BLOCKED], n_blocked);
+    block_add_stat(&st.stats[ST_SHADOW_TESTS_TRI], t_tri);
+    block_add_stat(&st.stats[ST_SHADOW_TESTS_SPH], t_sph);
+    block_add_stat(&st.stats[ST_SHADOW_TESTS_ELL], t_ell);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_shade: lights [first_light, first_light + n_group) in order; the last group also reflects
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t n_group, uint32_t last_group) {
+    const uint32_t n_rays = st.counts[bounce + 1];
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_rays) return;
+    const uint32_t s = st.list[(bounce + 1) & 1u][i];
+    const uint32_t id = st.hit_id[s];
+    const uint32_t kind = id >> 30, index = id & 0x3FFFFFFFu;
+    const float* mat = kind == 0 ? sc.tri_mat : (kind == 1 ? sc.sph_mat : sc.ell_mat);
+    const uint32_t mat_count = kind == 0 ? sc.n_tri_mat : (kind == 1 ? sc.n_sph_mat : sc.n_ell_mat);
+    float m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (index < mat_count) for (int k = 0; k < 10; ++k) m[k] = mat[index * 10 + k];
+
+    const V3 p{st.px[s], st.py[s], st.pz[s]};
+    const V3 n{st.nx[s], st.ny[s], st.nz[s]};
+    const V3 d{st.dx[s], st.dy[s], st.dz[s]};
+    float c[3] = {st.cr[s], st.cg[s], st.cb[s]};
+    float w[3] = {st.wr[s], st.wg[s], st.wb[s]};
+    const V3 to_eye = scale(-1.0f, d);                                    // ray_tracing.cpp:684
+    const uint32_t blocked = st.blocked[s];
+
+    for (uint32_t g = 0; g < n_group; ++g) {
+        if (blocked & (1u << g)) continue;
+        const float* L = sc.lights + (first_light + g) * 8;
+        const V3 lv{L[1], L[2], L[3]};
+        V3 to_light;
+        float scale_r = L[4], scale_g = L[5], scale_b = L[6];
+        if (L[0] != 0.0f) {                                               // point light, ray_tracing.cpp:709-722
+            const V3 full = sub(lv, p);
+            const float dist = sqrt_(sdot(full, full));
+            to_light = divide(full, dist);
+            const float linear_term = sc.atten[1] * dist;                 // ray_tracing.cpp:328-334
+            const float quadratic_term = sc.atten[2] * dist * dist;
+            const float att = 1.0f / (sc.atten[0] + linear_term + quadratic_term);
+            scale_r = att * L[4]; scale_g = att * L[5]; scale_b = att * L[6];
+        } else {                                                          // directional, ray_tracing.cpp:690-700
+            to_light = scale(-1.0f, lv);
+        }
+        const float di = fp_max(sdot(n, to_light), 0.0f);
+        const V3 half = normalise(add(to_eye, to_light));
+        const float si = fp_pow(fp_max(sdot(n, half), 0.0f), m[9]);
+        c[0] += w[0] * (scale_r * (di * m[0] + si * m[3]));
+        c[1] += w[1] * (scale_g * (di * m[1] + si * m[4]));
+        c[2] += w[2] * (scale_b * (di * m[2] + si * m[5]));
+    }
+    st.cr[s] = c[0]; st.cg[s] = c[1]; st.cb[s] = c[2];
+    if (last_group) {
+        st.blocked[s] = 0u;
+        st.wr[s] = w[0] * m[3]; st.wg[s] = w[1] * m[4]; st.wb[s] = w[2] * m[5];   // ray_tracing.cpp:726
+        const V3 above = add(p, scale(2.0f * TOL, n));
+        st.ox[s] = above.x; st.oy[s] = above.y; st.oz[s] = above.z;
+        const V3 refl = sub(d, scale(2.0f * sdot(d, n), n));              // ray_tracing.cpp:728, not renormalised
+        st.dx[s] = refl.x; st.dy[s] = refl.y; st.dz[s] = refl.z;
+    } else {
+        st.blocked[s] = 0u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_resolve: one thread per pixel of the chunk's tiles
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_resolve(State st, uint32_t first_tile_slot, uint8_t* __restrict__ tiles_out) {
+    const uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x;  // chunk-local pixel; the grid is exact (256 pixels per tile)
+    const uint32_t s0 = pixel * RT_SAMPLES_PER_PIXEL;
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    for (uint32_t k = 0; k < RT_SAMPLES_PER_PIXEL; ++k) { r += st.cr[s0 + k]; g += st.cg[s0 + k]; b += st.cb[s0 + k]; }
+    r = 0.0625f * r; g = 0.0625f * g; b = 0.0625f * b;                   // render_work_queue.cpp:51
+    // truncating conversion, low byte kept: what the x86 build of render_work_queue.cpp:53-55 does
+    uint8_t* out = tiles_out + (static_cast<size_t>(first_tile_slot) * 256 + pixel) * 3;
+    out[0] = static_cast<uint8_t>(static_cast<int>(r * 255.0f) & 0xFF);
+    out[1] = static_cast<uint8_t>(static_cast<int>(g * 255.0f) & 0xFF);
+    out[2] = static_cast<uint8_t>(static_cast<int>(b * 255.0f) & 0xFF);
+}
+
+// Tile buffers (rank-major) -> row-major image of the rectangle.
+__global__ void __launch_bounds__(BLOCK) k_assemble(const uint8_t* __restrict__ tiles, uint32_t stride_tiles, uint32_t world,
+                                                     uint32_t rect_w, uint32_t rect_h, uint32_t tiles_x, uint8_t* __restrict__ rgb) {
+    const uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= rect_w * rect_h) return;
+    const uint32_t x = idx % rect_w, y = idx / rect_w;
+    const uint32_t tile = (y / RT_TILE) * tiles_x + x / RT_TILE;
+    const uint32_t rank = tile % world, slot = tile / world;
+    const uint8_t* src = tiles + ((static_cast<size_t>(rank) * stride_tiles + slot) * 256 + (y % RT_TILE) * RT_TILE + x % RT_TILE) * 3;
+    uint8_t* dst = rgb + static_cast<size_t>(idx) * 3;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+}
+
+// Chunk-local primary ids -> [y][x][sample] of the rectangle.
+__global__ void __launch_bounds__(BLOCK) k_scatter_ids(const uint32_t* __restrict__ chunk_ids, uint32_t first_tile_slot, uint32_t n_samples,
+                                                        Frame f, uint32_t* __restrict__ out) {
+    const uint32_t s = blockIdx.x * BLOCK + threadIdx.x;
+    if (s >= n_samples) return;
+    const uint32_t tile = (first_tile_slot + s / SAMPLES_PER_TILE) * f.tile_world + f.tile_rank;
+    const uint32_t in_tile = s % SAMPLES_PER_TILE;
+    const uint32_t pixel = in_tile / RT_SAMPLES_PER_PIXEL, sample = in_tile % RT_SAMPLES_PER_PIXEL;
+    const uint32_t rx = (tile % f.tiles_x) * RT_TILE + pixel % RT_TILE;
+    const uint32_t ry = (tile / f.tiles_x) * RT_TILE + pixel / RT_TILE;
+    if (rx < f.rect_w && ry < f.rect_h) out[(static_cast<size_t>(ry) * f.rect_w + rx) * RT_SAMPLES_PER_PIXEL + sample] = chunk_ids[s];
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct Library {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    // per-chunk sample state, grown on demand
+    void* state_mem = nullptr;
+    size_t state_samples = 0;
+    uint32_t* counts = nullptr;             // 64 words
+    unsigned long long* stats = nullptr;    // ST_COUNT words
+    std::vector<hipEvent_t> events;
+};
+Library g_lib;
+
+constexpr int RAYS_PER_LANE = 2;
+constexpr uint32_t DEFAULT_CHUNK_TILES = 2048;   // 8.4 M samples
+constexpr uint32_t MAX_BOUNCES = 62;
+
+inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+struct Rect { uint32_t x0, y0, w, h, tiles_x, tiles_y, tiles; };
+Rect rect_of(const rt_render_params& p) {
+    Rect r;
+    if (p.rect_w) { r.x0 = p.rect_x0; r.y0 = p.rect_y0; r.w = p.rect_w; r.h = p.rect_h; }
+    else { r.x0 = 0; r.y0 = 0; r.w = p.width; r.h = p.height; }
+    r.tiles_x = ceil_div(r.w, RT_TILE);
+    r.tiles_y = ceil_div(r.h, RT_TILE);
+    r.tiles = r.tiles_x * r.tiles_y;
+    return r;
+}
+uint32_t rank_tiles(const rt_render_params& p) {
+    const Rect r = rect_of(p);
+    const uint32_t world = p.tile_world ? p.tile_world : 1, rank = p.tile_rank;
+    if (rank >= world) return 0;
+    return (r.tiles + world - 1 - rank) / world;
+}
+
+}  // namespace
+
+struct rt_scene {
+    DevScene dev;
+    std::vector<void*> allocations;
+};
+
+namespace {
+
+int ensure_state(size_t samples) {
+    if (g_lib.state_samples >= samples) return 0;
+    if (g_lib.state_mem) { HIP_TRY(hipFree(g_lib.state_mem)); g_lib.state_mem = nullptr; g_lib.state_samples = 0; }
+    // 18 float arrays + hit_id + blocked + 2 lists + primary ids = 23 words per sample
+    HIP_TRY(hipMalloc(&g_lib.state_mem, samples * 23 * sizeof(float)));
+    g_lib.state_samples = samples;
+    return 0;
+}
+
+State make_state(size_t samples, bool want_ids) {
+    State st;
+    float* f = static_cast<float*>(g_lib.state_mem);
+    float** fields[] = {&st.ox, &st.oy, &st.oz, &st.dx, &st.dy, &st.dz, &st.wr, &st.wg, &st.wb, &st.cr, &st.cg, &st.cb,
+                        &st.px, &st.py, &st.pz, &st.nx, &st.ny, &st.nz};
+    size_t k = 0;
+    for (float** field : fields) *field = f + samples * k++;
+    uint32_t* u = reinterpret_cast<uint32_t*>(f + samples * k);
+    st.hit_id = u; st.blocked = u + samples; st.list[0] = u + 2 * samples; st.list[1] = u + 3 * samples;
+    st.primary_id = want_ids ? u + 4 * samples : nullptr;
+    st.counts = g_lib.counts;
+    st.stats = g_lib.stats;
+    return st;
+}
+
+struct Timer {
+    // pairs of events around launches of one kernel family; resolved after the stream is idle
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans[2];
+    size_t next_event = 0;
+    hipEvent_t take() {
+        if (next_event == g_lib.events.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            g_lib.events.push_back(e);
+        }
+        return g_lib.events[next_event++];
+    }
+};
+
+template <typename Launch>
+void timed(Timer* timer, int family, Launch&& launch) {
+    if (!timer) { launch(); return; }
+    hipEvent_t a = timer->take(), b = timer->take();
+    if (a) (void)hipEventRecord(a, g_lib.stream);
+    launch();
+    if (b) (void)hipEventRecord(b, g_lib.stream);
+    if (a && b) timer->spans[family].push_back({a, b});
+}
+
+int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_render_params* prm, uint8_t* tiles_dev,
+                uint32_t* ids_dev /* rect-shaped, nullable */, rt_stats* stats) {
+    if (!g_lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    if (!scene || !cam || !prm) return rt_fail(RT_ERR_ARGUMENT, "null argument");
+    if (prm->width == 0 || prm->height == 0) return rt_fail(RT_ERR_ARGUMENT, "image size is zero");
+    if (prm->max_bounce_count < 0 || static_cast<uint32_t>(prm->max_bounce_count) > MAX_BOUNCES) return rt_fail(RT_ERR_LIMIT, "max_bounce_count out of range (0..62)");
+    const Rect rect = rect_of(*prm);
+    if (rect.x0 + rect.w > prm->width || rect.y0 + rect.h > prm->height || rect.w == 0 || rect.h == 0) return rt_fail(RT_ERR_ARGUMENT, "rectangle outside the image");
+    const uint32_t world = prm->tile_world ? prm->tile_world : 1;
+    if (prm->tile_rank >= world) return rt_fail(RT_ERR_ARGUMENT, "tile_rank >= tile_world");
+    const uint32_t my_tiles = rank_tiles(*prm);
+    uint32_t chunk_tiles = prm->chunk_tiles ? prm->chunk_tiles : DEFAULT_CHUNK_TILES;
+    if (chunk_tiles > 65536) chunk_tiles = 65536;
+    if (chunk_tiles > my_tiles) chunk_tiles = my_tiles ? my_tiles : 1;
+    const size_t chunk_samples = static_cast<size_t>(chunk_tiles) * SAMPLES_PER_TILE;
+    if (int rc = ensure_state(chunk_samples)) return rc;
+
+    const DevScene& sc = scene->dev;
+    Frame f;
+    std::memcpy(f.eye, cam->eye, sizeof f.eye);
+    std::memcpy(f.bi, cam->basis_i, sizeof f.bi);
+    std::memcpy(f.bj, cam->basis_j, sizeof f.bj);
+    std::memcpy(f.bk, cam->basis_k, sizeof f.bk);
+    std::memcpy(f.hw, cam->half_world, sizeof f.hw);
+    f.half_w_px = 0.5f * static_cast<float>(prm->width);      // render_work_queue.cpp:32-35
+    f.half_h_px = 0.5f * static_cast<float>(prm->height);
+    f.rect_x0 = rect.x0; f.rect_y0 = rect.y0; f.rect_w = rect.w; f.rect_h = rect.h;
+    f.tiles_x = rect.tiles_x; f.tile_rank = prm->tile_rank; f.tile_world = world;
+
+    State st = make_state(chunk_samples, ids_dev != nullptr);
+    hipStream_t stream = g_lib.stream;
+    HIP_TRY(hipMemsetAsync(g_lib.stats, 0, ST_COUNT * sizeof(unsigned long long), stream));
+
+    Timer timer_storage;
+    Timer* timer = stats ? &timer_storage : nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    if (timer) { ev_begin = timer->take(); ev_end = timer->take(); if (ev_begin) HIP_TRY(hipEventRecord(ev_begin, stream)); }
+
+    const uint32_t depth = static_cast<uint32_t>(prm->max_bounce_count);
+    for (uint32_t first = 0; first < my_tiles; first += chunk_tiles) {
+        const uint32_t n_tiles = (my_tiles - first < chunk_tiles) ? my_tiles - first : chunk_tiles;
+        const uint32_t n_samples = n_tiles * SAMPLES_PER_TILE;
+        HIP_TRY(hipMemsetAsync(g_lib.counts, 0, 64 * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(k_primary, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, f, sc, st, first);
+        const uint32_t scan_blocks = ceil_div(n_samples, BLOCK * RAYS_PER_LANE);
+        for (uint32_t b = 0; b < depth; ++b) {
+            timed(timer, 0, [&] { hipLaunchKernelGGL(k_closest<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b); });
+            if (sc.n_lights == 0) {
+                hipLaunchKernelGGL(k_shade, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, sc, st, b, 0u, 0u, 1u);
+            } else {
+                for (uint32_t l0 = 0; l0 < sc.n_lights; l0 += 32) {
+                    const uint32_t group = (sc.n_lights - l0 < 32) ? sc.n_lights - l0 : 32;
+                    timed(timer, 1, [&] { hipLaunchKernelGGL(k_shadow<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0); });
+                    hipLaunchKernelGGL(k_shade, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, sc, st, b, l0, group, (l0 + group == sc.n_lights) ? 1u : 0u);
+                }
+            }
+        }
+        hipLaunchKernelGGL(k_resolve, dim3(n_tiles), dim3(BLOCK), 0, stream, st, first, tiles_dev);
+        if (ids_dev) hipLaunchKernelGGL(k_scatter_ids, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, st.primary_id, first, n_samples, f, ids_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    if (timer && ev_end) HIP_TRY(hipEventRecord(ev_end, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+
+    if (stats) {
+        unsigned long long h[ST_COUNT];
+        HIP_TRY(hipMemcpy(h, g_lib.stats, sizeof h, hipMemcpyDeviceToHost));
+        std::memset(stats, 0, sizeof *stats);
+        stats->samples = h[ST_SAMPLES]; stats->culled = h[ST_CULLED];
+        stats->closest_rays = h[ST_CLOSEST_RAYS]; stats->hits = h[ST_HITS];
+        stats->shadow_rays = h[ST_SHADOW_RAYS]; stats->shadow_blocked = h[ST_SHADOW_BLOCKED];
+        const uint64_t real_counts[3] = {sc.n_tri_mat, sc.n_sph_mat, sc.n_ell_mat};
+        for (int k = 0; k < 3; ++k) stats->closest_tests[k] = stats->closest_rays * real_counts[k];
+        stats->shadow_tests[0] = h[ST_SHADOW_TESTS_TRI]; stats->shadow_tests[1] = h[ST_SHADOW_TESTS_SPH]; stats->shadow_tests[2] = h[ST_SHADOW_TESTS_ELL];
+        stats->full_tests = h[ST_FULL_TESTS];
+        float ms = 0.0f;
+        if (ev_begin && ev_end && hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) stats->device_ms = ms;
+        double family_ms[2] = {0.0, 0.0};
+        for (int fam = 0; fam < 2; ++fam)
+            for (auto& span : timer->spans[fam]) if (hipEventElapsedTime(&ms, span.first, span.second) == hipSuccess) family_ms[fam] += ms;
+        stats->closest_ms = family_ms[0]; stats->shadow_ms = family_ms[1];
+        stats->closest_launches = timer->spans[0].size(); stats->shadow_launches = timer->spans[1].size();
+    }
+    return 0;
+}
+
+template <typename T>
+int upload(rt_scene* s, const T* host, size_t count, T** dev) {
+    *dev = nullptr;
+    if (count == 0) return 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(dev), count * sizeof(T)));
+    s->allocations.push_back(*dev);
+    if (host) HIP_TRY(hipMemcpyAsync(*dev, host, count * sizeof(T), hipMemcpyHostToDevice, g_lib.stream));
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* rt_last_error(void) { return g_last_error.c_str(); }
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+int rt_init(int device) {
+    if (g_lib.ready && g_lib.device == device) return 0;
+    if (g_lib.ready) return rt_fail(RT_ERR_ARGUMENT, "rt_init: already initialised on another device");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return rt_fail(RT_ERR_ARGUMENT, "rt_init: no such device");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&g_lib.stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_lib.counts), 64 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_lib.stats), ST_COUNT * sizeof(unsigned long long)));
+    g_lib.device = device;
+    g_lib.ready = true;
+    return 0;
+}
+
+void rt_scene_destroy(rt_scene* scene) {
+    if (!scene) return;
+    for (void* p : scene->allocations) (void)hipFree(p);
+    delete scene;
+}
+
+int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
+    if (!g_lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    if (!desc || !out) return rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: null argument");
+    *out = nullptr;
+    if (desc->n_triangle8 > (1u << 26) || desc->n_sphere8 > (1u << 26) || desc->n_ellipsoid8 > (1u << 26)) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^29 primitives of one kind");
+    if (desc->n_triangles > desc->n_triangle8 * 8 || desc->n_spheres > desc->n_sphere8 * 8 || desc->n_ellipsoids > desc->n_ellipsoid8 * 8) return rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: more materials than primitive slots");
+    if (desc->n_point_lights > 4096) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 4096 point lights");
+    rt_scene* s = new rt_scene();
+    auto fail = [&](int rc) { rt_scene_destroy(s); return rc; };
+    DevScene& d = s->dev;
+    std::memset(&d, 0, sizeof d);
+    hipStream_t stream = g_lib.stream;
+    int rc;
+
+    d.tri_nb = static_cast<uint32_t>(desc->n_triangle8); d.n_tri = 8u * d.tri_nb;
+    d.sph_nb = static_cast<uint32_t>(desc->n_sphere8); d.n_sph = 8u * d.sph_nb;
+    d.ell_nb = static_cast<uint32_t>(desc->n_ellipsoid8); d.n_ell = 8u * d.ell_nb;
+    d.n_tri_mat = static_cast<uint32_t>(desc->n_triangles);
+    d.n_sph_mat = static_cast<uint32_t>(desc->n_spheres);
+    d.n_ell_mat = static_cast<uint32_t>(desc->n_ellipsoids);
+
+    float *raw_tri, *raw_sph, *raw_inv, *raw_fwd, *raw_pl;
+    if ((rc = upload(s, desc->triangle8s, static_cast<size_t>(d.tri_nb) * 72, &raw_tri))) return fail(rc);
+    if ((rc = upload(s, desc->sphere8s, static_cast<size_t>(d.sph_nb) * 32, &raw_sph))) return fail(rc);
+    if ((rc = upload(s, desc->ellipsoid8_inverse_transforms, static_cast<size_t>(d.ell_nb) * 96, &raw_inv))) return fail(rc);
+    if ((rc = upload(s, desc->ellipsoid8_transforms, static_cast<size_t>(d.ell_nb) * 96, &raw_fwd))) return fail(rc);
+    if ((rc = upload(s, desc->point_light_sources, static_cast<size_t>(desc->n_point_lights) * 6, &raw_pl))) return fail(rc);
+    float *tri_mat, *sph_mat, *ell_mat;
+    if ((rc = upload(s, desc->triangle_materials, static_cast<size_t>(d.n_tri_mat) * 10, &tri_mat))) return fail(rc);
+    if ((rc = upload(s, desc->sphere_materials, static_cast<size_t>(d.n_sph_mat) * 10, &sph_mat))) return fail(rc);
+    if ((rc = upload(s, desc->ellipsoid_materials, static_cast<size_t>(d.n_ell_mat) * 10, &ell_mat))) return fail(rc);
+    d.tri_mat = tri_mat; d.sph_mat = sph_mat; d.ell_mat = ell_mat;
+
+    float4 *tri, *sph, *ell, *ell_light;
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &tri))) return fail(rc);
+    if ((rc = upload<float4>(s, nullptr, d.n_sph, &sph))) return fail(rc);
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * 6, &ell))) return fail(rc);
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * desc->n_point_lights, &ell_light))) return fail(rc);
+    if (d.n_tri) hipLaunchKernelGGL(k_prep_triangles, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, raw_tri, d.tri_nb, tri);
+    if (d.n_sph) hipLaunchKernelGGL(k_prep_spheres, dim3(ceil_div(d.n_sph, BLOCK)), dim3(BLOCK), 0, stream, raw_sph, d.sph_nb, sph);
+    if (d.n_ell) hipLaunchKernelGGL(k_prep_ellipsoids, dim3(ceil_div(d.n_ell, BLOCK)), dim3(BLOCK), 0, stream, raw_inv, raw_fwd, d.ell_nb, ell);
+    if (d.n_ell && desc->n_point_lights)
+        hipLaunchKernelGGL(k_prep_ellipsoid_lights, dim3(ceil_div(d.n_ell, BLOCK)), dim3(BLOCK), 0, stream, ell, d.n_ell, raw_pl, static_cast<uint32_t>(desc->n_point_lights), ell_light);
+    d.tri = tri; d.sph = sph; d.ell = ell; d.ell_light = ell_light;
+
+    // light table: the directional light first (ray_tracing.cpp:687), then the point lights in file order (:704)
+    std::vector<float> lights;
+    d.has_directional = desc->has_directional_light ? 1u : 0u;
+    if (d.has_directional) {
+        const float* L = desc->directional_light;
+        lights.insert(lights.end(), {0.0f, L[0], L[1], L[2], L[3], L[4], L[5], 0.0f});
+    }
+    for (uint64_t l = 0; l < desc->n_point_lights; ++l) {
+        const float* L = desc->point_light_sources + l * 6;
+        lights.insert(lights.end(), {1.0f, L[0], L[1], L[2], L[3], L[4], L[5], 0.0f});
+    }
+    d.n_lights = static_cast<uint32_t>(lights.size() / 8);
+    float* lights_dev;
+    if ((rc = upload(s, lights.data(), lights.size(), &lights_dev))) return fail(rc);
+    d.lights = lights_dev;
+    std::memcpy(d.bb, desc->bounding_box, sizeof d.bb);
+    std::memcpy(d.ambient, desc->ambient, sizeof d.ambient);
+    std::memcpy(d.atten, desc->attenuation, sizeof d.atten);
+
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return fail(rt_fail(RT_ERR_DEVICE, "rt_scene_create: scene preparation kernels failed"));
+    *out = s;
+    return 0;
+}
+
+uint32_t rt_rank_tile_count(const rt_render_params* params) { return params ? rank_tiles(*params) : 0; }
+uint32_t rt_total_tile_count(const rt_render_params* params) { return params ? rect_of(*params).tiles : 0; }
+
+int rt_render_tiles_device(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params, void* tiles_dev, rt_stats* stats) {
+    if (!tiles_dev) return rt_fail(RT_ERR_ARGUMENT, "rt_render_tiles_device: null output");
+    return render_impl(scene, camera, params, static_cast<uint8_t*>(tiles_dev), nullptr, stats);
+}
+
+int rt_assemble_tiles_device(const void* gathered, uint32_t stride_tiles, const rt_render_params* params, void* rgb_dev) {
+    if (!g_lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    if (!gathered || !params || !rgb_dev) return rt_fail(RT_ERR_ARGUMENT, "rt_assemble_tiles_device: null argument");
+    const Rect rect = rect_of(*params);
+    const uint32_t world = params->tile_world ? params->tile_world : 1;
+    hipLaunchKernelGGL(k_assemble, dim3(ceil_div(rect.w * rect.h, BLOCK)), dim3(BLOCK), 0, g_lib.stream,
+                       static_cast<const uint8_t*>(gathered), stride_tiles, world, rect.w, rect.h, rect.tiles_x, static_cast<uint8_t*>(rgb_dev));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g_lib.stream));
+    return 0;
+}
+
+int rt_render(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params, uint8_t* rgb_out, uint32_t* primary_id_out, rt_stats* stats) {
+    if (!g_lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    if (!params || !rgb_out) return rt_fail(RT_ERR_ARGUMENT, "rt_render: null argument");
+    const Rect rect = rect_of(*params);
+    const uint32_t world = params->tile_world ? params->tile_world : 1;
+    const uint32_t my_tiles = rank_tiles(*params);
+    const size_t n_px = static_cast<size_t>(rect.w) * rect.h;
+    uint8_t *tiles_dev = nullptr, *rgb_dev = nullptr;
+    uint32_t* ids_dev = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() { if (tiles_dev) (void)hipFree(tiles_dev); if (rgb_dev) (void)hipFree(rgb_dev); if (ids_dev) (void)hipFree(ids_dev); };
+    if (hipMalloc(reinterpret_cast<void**>(&tiles_dev), static_cast<size_t>(my_tiles ? my_tiles : 1) * 768) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&rgb_dev), n_px * 3) != hipSuccess ||
+        (primary_id_out && hipMalloc(reinterpret_cast<void**>(&ids_dev), n_px * 16 * sizeof(uint32_t)) != hipSuccess)) {
+        cleanup();
+        return rt_fail(RT_ERR_DEVICE, "rt_render: out of device memory");
+    }
+    if (primary_id_out && hipMemsetAsync(ids_dev, 0xFF, n_px * 16 * sizeof(uint32_t), g_lib.stream) != hipSuccess) { cleanup(); return rt_fail(RT_ERR_DEVICE, "rt_render: memset failed"); }
+    rc = render_impl(scene, camera, params, tiles_dev, ids_dev, stats);
+    if (rc == 0) {
+        if (world == 1) {
+            rc = rt_assemble_tiles_device(tiles_dev, my_tiles, params, rgb_dev);
+            if (rc == 0 && hipMemcpy(rgb_out, rgb_dev, n_px * 3, hipMemcpyDeviceToHost) != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_render: copy back failed");
+        } else {
+            // only this rank's tiles are defined: copy them pixel by pixel into the caller's image
+            std::vector<uint8_t> tiles(static_cast<size_t>(my_tiles) * 768);
+            if (my_tiles && hipMemcpy(tiles.data(), tiles_dev, tiles.size(), hipMemcpyDeviceToHost) != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_render: copy back failed");
+            for (uint32_t slot = 0; rc == 0 && slot < my_tiles; ++slot) {
+                const uint32_t tile = slot * world + params->tile_rank;
+                const uint32_t tx = tile % rect.tiles_x, ty = tile / rect.tiles_x;
+                for (uint32_t py = 0; py < RT_TILE; ++py)
+                    for (uint32_t px = 0; px < RT_TILE; ++px) {
+                        const uint32_t x = tx * RT_TILE + px, y = ty * RT_TILE + py;
+                        if (x < rect.w && y < rect.h) std::memcpy(rgb_out + (static_cast<size_t>(y) * rect.w + x) * 3, tiles.data() + (static_cast<size_t>(slot) * 256 + py * RT_TILE + px) * 3, 3);
+                    }
+            }
+        }
+        if (rc == 0 && primary_id_out && hipMemcpy(primary_id_out, ids_dev, n_px * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_render: id copy back failed");
+    }
+    cleanup();
+    return rc;
+}
+
+int rt_render_file_info(const rt_file_info* info, uint8_t* rgb_out, rt_stats* stats) {
+    if (!info || !rgb_out) return rt_fail(RT_ERR_ARGUMENT, "rt_render_file_info: null argument");
+    rt_camera_desc cam;
+    rt_camera_setup(info->camera, &cam);
+    rt_scene* scene = nullptr;
+    int rc = rt_scene_create(&info->desc, &scene);
+    if (rc) return rc;
+    rt_render_params p;
+    std::memset(&p, 0, sizeof p);
+    p.width = info->width; p.height = info->height; p.max_bounce_count = info->max_recursion_depth;
+    rc = rt_render(scene, &cam, &p, rgb_out, nullptr, stats);
+    rt_scene_destroy(scene);
+    return rc;
+}
+
+}  // extern "C"
