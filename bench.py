@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the render loop: one step = one full frame of the workload, image tiles split
+over the ranks (one process per GPU), framebuffer assembled on rank 0 from an RCCL all-gather.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload scene7_4k|scene1|...|synthetic]
+
+Prints one JSON line on rank 0 (see README / DESIGN.md for the fields).  For N > 1 launch with
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic FLOPs per ray-primitive test: FMA = 2, add/sub/mul/div/sqrt = 1, compare/select = 0
+FLOP_TRI, FLOP_SPH, FLOP_ELL_CLOSEST, FLOP_ELL_SHADOW_POINT, FLOP_ELL_SHADOW_DIR = 54, 19, 95, 71, 62
+PEAK_FP32_TFLOPS = 157.3   # MI355X FP32 vector peak: 256 CU x 4 SIMD x 32 lanes x 2 FLOP x 2.4 GHz
+TILE_BYTES = 768
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="scene7_4k")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--maxdepth", type=int, default=-1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crop", default="240x135", help="centred crop the CPU baseline renders (WxH)")
+    return ap.parse_args()
+
+
+def load_workload(api, name, width, height, maxdepth):
+    """Returns (FileInfo, label)."""
+    scenes = os.path.join(ROOT, "tests", "golden", "scenes")
+    if name == "scene7_4k":
+        fi = api.FileInfo(os.path.join(scenes, "scene7.test"))
+        fi.set_size(width or 3840, height or 2160)
+    elif name == "synthetic":
+        from raytracer_amd import synth
+        path = synth.ensure_scene_file()
+        fi = api.FileInfo(path)
+        if width and height:
+            fi.set_size(width, height)
+    else:
+        fi = api.FileInfo(os.path.join(scenes, name + ".test"))
+        if width and height:
+            fi.set_size(width, height)
+    label = "%s@%dx%d" % (name.replace("_4k", ""), fi.width, fi.height)
+    return fi, label
+
+
+def flops_of(stats, n_point_lights_share=1.0):
+    closest = stats.closest_tests[0] * FLOP_TRI + stats.closest_tests[1] * FLOP_SPH + stats.closest_tests[2] * FLOP_ELL_CLOSEST
+    shadow = stats.shadow_tests[0] * FLOP_TRI + stats.shadow_tests[1] * FLOP_SPH + stats.shadow_tests[2] * FLOP_ELL_SHADOW_POINT
+    return closest, shadow
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (args.gpus, world))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import abi, api
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    api.init(local_rank)
+
+    fi, label = load_workload(api, args.workload, args.width, args.height, args.maxdepth)
+    depth = fi.max_recursion_depth if args.maxdepth < 0 else args.maxdepth
+    cam = fi.camera()
+    scene = api.Scene(fi.scene_desc)
+    prm = fi.params(max_bounce_count=depth, tile_rank=rank, tile_world=world)
+    total_tiles = api.total_tile_count(prm)
+    stride = (total_tiles + world - 1) // world
+    my_tiles = api.rank_tile_count(prm)
+
+    tiles = torch.zeros(stride * TILE_BYTES, dtype=torch.uint8, device=device)
+    gathered = torch.zeros(world * stride * TILE_BYTES, dtype=torch.uint8, device=device) if world > 1 else tiles
+    frame = torch.zeros(fi.height * fi.width * 3, dtype=torch.uint8, device=device) if rank == 0 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        st = scene.render_tiles_device(cam, prm, tiles.data_ptr(), want_stats=True)   # returns with its stream idle
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, tiles)     # RCCL over xGMI: the framebuffer exchange
+            torch.cuda.synchronize()
+        if rank == 0:
+            api.assemble_tiles_device(gathered.data_ptr(), stride, prm, frame.data_ptr())
+        return st
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(args.steps):
+        stats.append(step())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-rank work counters of the timed steps, summed over ranks
+    fields = ["closest_rays", "shadow_rays", "samples", "culled", "hits", "shadow_blocked", "full_tests"]
+    local = [float(sum(getattr(s, f) for s in stats)) for f in fields]
+    local += [float(sum(s.closest_tests[k] for s in stats)) for k in range(3)]
+    local += [float(sum(s.shadow_tests[k] for s in stats)) for k in range(3)]
+    local += [sum(s.closest_ms for s in stats), sum(s.shadow_ms for s in stats), sum(s.device_ms for s in stats)]
+    local += [float(sum(s.closest_launches for s in stats)), float(sum(s.shadow_launches for s in stats))]
+    acc = torch.tensor(local, dtype=torch.float64, device=device)
+    mx = acc.clone()
+    if world > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    tot = dict(zip(fields + ["ct_tri", "ct_sph", "ct_ell", "st_tri", "st_sph", "st_ell", "closest_ms", "shadow_ms", "device_ms",
+                             "closest_launches", "shadow_launches"], acc.tolist()))
+    rank_max = dict(zip(["closest_ms", "shadow_ms", "device_ms"], mx.tolist()[13:16]))
+
+    if rank == 0:
+        rays = tot["closest_rays"] + tot["shadow_rays"]
+        tests = tot["ct_tri"] + tot["ct_sph"] + tot["ct_ell"] + tot["st_tri"] + tot["st_sph"] + tot["st_ell"]
+        closest_flop = tot["ct_tri"] * FLOP_TRI + tot["ct_sph"] * FLOP_SPH + tot["ct_ell"] * FLOP_ELL_CLOSEST
+        shadow_flop = tot["st_tri"] * FLOP_TRI + tot["st_sph"] * FLOP_SPH + tot["st_ell"] * FLOP_ELL_SHADOW_POINT
+        # dominant kernel: k_closest. Per-GPU figure: this rank-summed FLOP over rank-summed kernel time.
+        closest_tflops = closest_flop / (tot["closest_ms"] * 1e-3) / 1e12 if tot["closest_ms"] > 0 else 0.0
+        shadow_tflops = shadow_flop / (tot["shadow_ms"] * 1e-3) / 1e12 if tot["shadow_ms"] > 0 else 0.0
+        out = {
+            "metric": "Mrays/s",
+            "value": rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic" if args.workload == "synthetic" else "reference scene file (tests/golden/scenes), size overridden",
+            "config": {"workload": label, "maxdepth": depth, "samples_per_pixel": 16,
+                       "primitives": {"triangles": int(fi.scene_desc.n_triangles), "spheres": int(fi.scene_desc.n_spheres),
+                                      "ellipsoids": int(fi.scene_desc.n_ellipsoids)},
+                       "lights": int(fi.scene_desc.n_point_lights) + int(fi.scene_desc.has_directional_light),
+                       "parallelism": "tiles%%%d" % world},
+            "ray_prim_tests_per_s": tests / elapsed,
+            "rays_per_step": rays / args.steps,
+            "tests_per_step": tests / args.steps,
+            "culled_samples_per_step": tot["culled"] / args.steps,
+            "roofline": {
+                "bound": "valu_fp32",
+                "kernel": "k_closest",
+                "achieved": closest_tflops,
+                "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": closest_tflops / PEAK_FP32_TFLOPS,
+                "traffic": None,
+                "flop_per_launch": closest_flop / max(tot["closest_launches"], 1.0),
+                "avg_launch_ms": tot["closest_ms"] / max(tot["closest_launches"], 1.0),
+                "launches": int(tot["closest_launches"]),
+                "shadow_kernel": {"kernel": "k_shadow", "achieved": shadow_tflops, "frac": shadow_tflops / PEAK_FP32_TFLOPS,
+                                  "avg_launch_ms": tot["shadow_ms"] / max(tot["shadow_launches"], 1.0), "launches": int(tot["shadow_launches"])},
+                "whole_step_tflops": (closest_flop + shadow_flop) / elapsed / 1e12 / world,
+            },
+            "per_rank_max_ms": {k: v / args.steps for k, v in rank_max.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(api, abi, fi, cam, scene, depth, args.cpu_crop)
+        print(json.dumps(out), flush=True)
+
+    scene.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(api, abi, fi, cam, scene, depth, crop):
+    """Time the CPU renderer on a centred crop of the same frame, on this box's host cores.
+
+    The unmodified reference (oracle/_ref/librt_ref.so, multithreaded over scanlines like its
+    work queue) when that library is present, else the scalar restatement in oracle/.  Ray counts
+    for the crop come from the GPU path, whose counters are identical to the oracle's.
+    """
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import checkers
+    cw, ch = [int(v) for v in crop.split("x")]
+    cw, ch = min(cw, fi.width), min(ch, fi.height)
+    prm = fi.params(max_bounce_count=depth, rect_x0=(fi.width - cw) // 2, rect_y0=(fi.height - ch) // 2, rect_w=cw, rect_h=ch)
+    g = scene.render(cam, prm)
+    rays = g["stats"].closest_rays + g["stats"].shadow_rays
+    threads = min(os.cpu_count() or 1, 16)
+    if checkers.have_ref():
+        lib, prefix, kind = checkers.load_ref(), "ref_", "reference"
+    else:
+        lib, prefix, kind = checkers.load_oracle(), "rto_", "port"
+    r = checkers.cpu_render(lib, prefix, fi.scene_desc, cam, prm, threads=threads)
+    same = bool((r["rgb"] == g["rgb"]).all())
+    return {"value": rays / r["seconds"] / 1e6, "unit": "Mrays/s", "cores": threads, "kind": kind,
+            "sample": "centred %dx%d-pixel crop of the same frame (%d rays), %.1f s" % (cw, ch, rays, r["seconds"]),
+            "seconds": r["seconds"], "image_identical_to_gpu": same}
+
+
+if __name__ == "__main__":
+    main()

@@ -64,6 +64,7 @@ constexpr uint32_t SAMPLES_PER_TILE = RT_TILE * RT_TILE * RT_SAMPLES_PER_PIXEL; 
 // smallest (distance, lane, batch), not the smallest index (ray_tracing.cpp:489-516).
 struct DevScene {
     const float4* tri;   // 4 x float4 per triangle: (a, n.x) (a_to_b, n.y) (a_to_c, n.z) (n.n, 0, 0, 0)
+    const float4* trif;  // pre-test records, 4 x float4 per triangle: (n, G) (a, H) (w1, 0) (w2, 0), see pretest_rejects
     const float4* sph;   // (centre, radius)
     const float4* ell;   // 6 x float4: rows of the inverse transform, rows of the transform
     const float4* ell_light;  // [point light][ellipsoid]: inverse transform applied to the light position
@@ -210,6 +211,37 @@ DEV float hit_triangle(V3 o, V3 d, float4 t0, float4 t1, float4 t2, float nn) {
     return (parallel | behind | outside) ? FLT_MAX : t;
 }
 
+// Conservative pre-test of one ray against one triangle: returns true only when the full
+// test above is certain to return FLT_MAX or a distance outside (t_min, t_max).  It is not part
+// of the reference; it exists because the full test spends most of its time in three IEEE
+// divisions, while almost every ray misses almost every triangle.
+//
+// With n, a and nn as in the full test, w1 = (n x a_to_b)/nn and w2 = (a_to_c x n)/nn, the
+// full test's barycentrics are alpha = w1.(p - a), beta = w2.(p - a) in real arithmetic.
+// Here t1 = ((a-o).n) * rcp(d.n) (same dot products as the full test, reciprocal instead of a
+// division), ap = t1*d - (a-o), alpha1 = w1.ap, beta1 = w2.ap.  A rounding analysis of both
+// evaluation orders ("Pre-test margin") bounds |alpha1 - alpha| and |beta1 - beta| by
+//     m = 130 eps Q (|o|_inf + |t| + |a|_inf) + eps,  Q = |n|_inf max(|a_to_b|_inf, |a_to_c|_inf)/nn,
+// eps = 2^-24.  The record carries G = 2^-16 Q (about twice 130 eps Q) and H = G |a|_inf + 2^-22,
+// so m <= G (|t1| + |o|_inf) + H, and a ray is rejected only if
+//     min(alpha1, beta1, 1 - alpha1 - beta1) < -2m,  or t1 outside [t_min, t_max],
+// with t_min, t_max widened by the caller by more than the reciprocal's error.  Any NaN or
+// infinity makes the comparisons false, i.e. "not rejected", and the full test decides.
+DEV bool pretest_rejects(V3 o, V3 d, float o_max, float t_min, float t_max, float4 f0, float4 f1, float4 f2, float4 f3) {
+    const V3 n = xyz(f0), a = xyz(f1), w1 = xyz(f2), w2 = xyz(f3);
+    const float dn = vdot(d, n);
+    const V3 ao = sub(a, o);
+    const float num = vdot(ao, n);
+    const float t1 = num * __builtin_amdgcn_rcpf(dn);
+    const V3 ap{fma_(t1, d.x, -ao.x), fma_(t1, d.y, -ao.y), fma_(t1, d.z, -ao.z)};
+    const float alpha = vdot(ap, w1);
+    const float beta = vdot(ap, w2);
+    const float rest = 1.0f - (alpha + beta);
+    const float u = __builtin_fminf(__builtin_fminf(alpha, beta), rest);
+    const float m2 = fma_(f0.w, __builtin_fabsf(t1) + o_max, f1.w);   // m
+    return (u < -2.0f * m2) | (t1 < t_min) | (t1 > t_max);
+}
+
 // ray_tracing.cpp:169-206; the far root is replaced by the near one at :202 and that is kept
 DEV float hit_sphere(V3 o, V3 d, float4 s) {
     const V3 oc = sub(xyz(s), o);
@@ -311,7 +343,7 @@ DEV void block_add_stat(unsigned long long* stat, unsigned long long value) {
 // ------------------------------------------------------------------------------------------
 // scene preparation: reference AoSoA-8 -> scan-ordered records
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLOCK) k_prep_triangles(const float* __restrict__ tri8, uint32_t nb, float4* __restrict__ out) {
+__global__ void __launch_bounds__(BLOCK) k_prep_triangles(const float* __restrict__ tri8, uint32_t nb, float4* __restrict__ out, float4* __restrict__ outf) {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= 8u * nb) return;
     const uint32_t j = k / nb, i = k % nb;
@@ -324,6 +356,20 @@ __global__ void __launch_bounds__(BLOCK) k_prep_triangles(const float* __restric
     o[1] = make_float4(ab.x, ab.y, ab.z, n.y);
     o[2] = make_float4(ac.x, ac.y, ac.z, n.z);
     o[3] = make_float4(nn, 0.0f, 0.0f, 0.0f);
+    // pre-test record (pretest_rejects): nothing here has to match the reference's rounding
+    const float inv_nn = 1.0f / nn;
+    const V3 w1 = scale(inv_nn, vcross(n, ab));
+    const V3 w2 = scale(inv_nn, vcross(ac, n));
+    const float n_max = fmaxf(fabsf(n.x), fmaxf(fabsf(n.y), fabsf(n.z)));
+    const float e_max = fmaxf(fmaxf(fabsf(ab.x), fmaxf(fabsf(ab.y), fabsf(ab.z))), fmaxf(fabsf(ac.x), fmaxf(fabsf(ac.y), fabsf(ac.z))));
+    const float a_max = fmaxf(fabsf(a.x), fmaxf(fabsf(a.y), fabsf(a.z)));
+    const float G = 1.0001f * (1.0f / 65536.0f) * (n_max * e_max * inv_nn);
+    const float H = 1.0001f * (G * a_max) + (1.0f / 4194304.0f);
+    float4* q = outf + static_cast<size_t>(k) * 4;
+    q[0] = make_float4(n.x, n.y, n.z, G);
+    q[1] = make_float4(a.x, a.y, a.z, H);
+    q[2] = make_float4(w1.x, w1.y, w1.z, 0.0f);
+    q[3] = make_float4(w2.x, w2.y, w2.z, 0.0f);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_prep_spheres(const float* __restrict__ sph8, uint32_t nb, float4* __restrict__ out) {
@@ -424,7 +470,7 @@ DEV void stage_tile(float4* lds, const float4* __restrict__ src, uint32_t first,
     for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) lds[i] = g[i];
 }
 
-template <int R>
+template <int R, bool FILTER>
 __global__ void __launch_bounds__(BLOCK) k_closest(DevScene sc, State st, uint32_t bounce) {
     __shared__ float4 lds[TILE_PRIMS * 6];
     __shared__ uint32_t lds_scan[8];
@@ -447,20 +493,43 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DevScene sc, State st, uint32
 
     // ---- triangles ----
     float tri_t[R]; uint32_t tri_k[R];
+    float tri_t_hi[R], o_max[R];   // pre-test only: widened current best, |o|_inf
+    unsigned long long n_full = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) { tri_t[r] = FLT_MAX; tri_k[r] = 0xFFFFFFFFu; }
+    for (int r = 0; r < R; ++r) {
+        tri_t[r] = FLT_MAX; tri_k[r] = 0xFFFFFFFFu; tri_t_hi[r] = __builtin_inff();
+        o_max[r] = fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z)));
+    }
+    const float4* __restrict__ tri_stream = FILTER ? sc.trif : sc.tri;
     for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
         __syncthreads();
-        stage_tile<4>(lds, sc.tri, first, count);
+        stage_tile<4>(lds, tri_stream, first, count);
         __syncthreads();
 #pragma unroll 2
         for (uint32_t k = 0; k < count; ++k) {
             const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
+            if (FILTER) {
+                bool survive = false;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float t = hit_triangle(o[r], d[r], t0, t1, t2, t3.x);
-                if (t < tri_t[r]) { tri_t[r] = t; tri_k[r] = first + k; }
+                for (int r = 0; r < R; ++r) survive |= !pretest_rejects(o[r], d[r], o_max[r], TOL * 0.99999f, tri_t_hi[r], t0, t1, t2, t3);
+                if (__any(survive)) {
+                    // some lane may hit: the whole wave runs the full test on the full record
+                    const float4* __restrict__ rec = sc.tri + static_cast<size_t>(first + k) * 4;
+                    const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float t = hit_triangle(o[r], d[r], e0, e1, e2, e3.x);
+                        if (t < tri_t[r]) { tri_t[r] = t; tri_k[r] = first + k; tri_t_hi[r] = t * 1.000001f; }
+                    }
+                    n_full += R;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float t = hit_triangle(o[r], d[r], t0, t1, t2, t3.x);
+                    if (t < tri_t[r]) { tri_t[r] = t; tri_k[r] = first + k; }
+                }
             }
         }
     }
@@ -568,12 +637,13 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DevScene sc, State st, uint32
     }
     block_add_stat(&st.stats[ST_CLOSEST_RAYS], n_valid);
     block_add_stat(&st.stats[ST_HITS], n_hit);
+    if (FILTER) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
 }
 
 // ------------------------------------------------------------------------------------------
 // k_shadow: any-hit of every hit point toward light (first_light + blockIdx.y)
 // ------------------------------------------------------------------------------------------
-template <int R>
+template <int R, bool FILTER>
 __global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, State st, uint32_t bounce, uint32_t first_light) {
     __shared__ float4 lds[TILE_PRIMS * 4];
     const uint32_t n_rays = st.counts[bounce + 1];
@@ -619,10 +689,18 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, State st, uint32_
     };
     bool done = wave_done();
 
+    float o_max[R], limit_hi[R];
+    unsigned long long n_full = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        o_max[r] = fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z)));
+        limit_hi[r] = limit[r] * 1.000001f;   // FLT_MAX becomes +inf: nothing is rejected for being too far
+    }
+    const float4* __restrict__ tri_stream = FILTER ? sc.trif : sc.tri;
     for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
         if (__syncthreads_and(done)) break;
-        stage_tile<4>(lds, sc.tri, first, count);
+        stage_tile<4>(lds, tri_stream, first, count);
         __syncthreads();
         if (!done) {
 #pragma unroll
@@ -630,8 +708,21 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, State st, uint32_
 #pragma unroll 2
             for (uint32_t k = 0; k < count; ++k) {
                 const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
+                if (FILTER) {
+                    bool survive = false;
 #pragma unroll
-                for (int r = 0; r < R; ++r) blocked[r] |= hit_triangle(o[r], d[r], t0, t1, t2, t3.x) < limit[r];
+                    for (int r = 0; r < R; ++r) survive |= !pretest_rejects(o[r], d[r], o_max[r], TOL * 0.99999f, limit_hi[r], t0, t1, t2, t3);
+                    if (__any(survive)) {
+                        const float4* __restrict__ rec = sc.tri + static_cast<size_t>(first + k) * 4;
+                        const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) blocked[r] |= hit_triangle(o[r], d[r], e0, e1, e2, e3.x) < limit[r];
+                        n_full += R;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) blocked[r] |= hit_triangle(o[r], d[r], t0, t1, t2, t3.x) < limit[r];
+                }
             }
             done = wave_done();
         }
@@ -690,6 +781,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, State st, uint32_
     block_add_stat(&st.stats[ST_SHADOW_TESTS_TRI], t_tri);
     block_add_stat(&st.stats[ST_SHADOW_TESTS_SPH], t_sph);
     block_add_stat(&st.stats[ST_SHADOW_TESTS_ELL], t_ell);
+    if (FILTER) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -929,6 +1021,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     if (timer) { ev_begin = timer->take(); ev_end = timer->take(); if (ev_begin) HIP_TRY(hipEventRecord(ev_begin, stream)); }
 
     const uint32_t depth = static_cast<uint32_t>(prm->max_bounce_count);
+    const bool filter = (prm->flags & RT_FLAG_NO_FILTER) == 0;
     for (uint32_t first = 0; first < my_tiles; first += chunk_tiles) {
         const uint32_t n_tiles = (my_tiles - first < chunk_tiles) ? my_tiles - first : chunk_tiles;
         const uint32_t n_samples = n_tiles * SAMPLES_PER_TILE;
@@ -936,13 +1029,19 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         hipLaunchKernelGGL(k_primary, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, f, sc, st, first);
         const uint32_t scan_blocks = ceil_div(n_samples, BLOCK * RAYS_PER_LANE);
         for (uint32_t b = 0; b < depth; ++b) {
-            timed(timer, 0, [&] { hipLaunchKernelGGL(k_closest<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b); });
+            timed(timer, 0, [&] {
+                if (filter) hipLaunchKernelGGL((k_closest<RAYS_PER_LANE, true>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+                else hipLaunchKernelGGL((k_closest<RAYS_PER_LANE, false>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+            });
             if (sc.n_lights == 0) {
                 hipLaunchKernelGGL(k_shade, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, sc, st, b, 0u, 0u, 1u);
             } else {
                 for (uint32_t l0 = 0; l0 < sc.n_lights; l0 += 32) {
                     const uint32_t group = (sc.n_lights - l0 < 32) ? sc.n_lights - l0 : 32;
-                    timed(timer, 1, [&] { hipLaunchKernelGGL(k_shadow<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0); });
+                    timed(timer, 1, [&] {
+                        if (filter) hipLaunchKernelGGL((k_shadow<RAYS_PER_LANE, true>), dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0);
+                        else hipLaunchKernelGGL((k_shadow<RAYS_PER_LANE, false>), dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0);
+                    });
                     hipLaunchKernelGGL(k_shade, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, sc, st, b, l0, group, (l0 + group == sc.n_lights) ? 1u : 0u);
                 }
             }
@@ -1055,17 +1154,18 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     if ((rc = upload(s, desc->ellipsoid_materials, static_cast<size_t>(d.n_ell_mat) * 10, &ell_mat))) return fail(rc);
     d.tri_mat = tri_mat; d.sph_mat = sph_mat; d.ell_mat = ell_mat;
 
-    float4 *tri, *sph, *ell, *ell_light;
+    float4 *tri, *trif, *sph, *ell, *ell_light;
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &tri))) return fail(rc);
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &trif))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, d.n_sph, &sph))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * 6, &ell))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * desc->n_point_lights, &ell_light))) return fail(rc);
-    if (d.n_tri) hipLaunchKernelGGL(k_prep_triangles, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, raw_tri, d.tri_nb, tri);
+    if (d.n_tri) hipLaunchKernelGGL(k_prep_triangles, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, raw_tri, d.tri_nb, tri, trif);
     if (d.n_sph) hipLaunchKernelGGL(k_prep_spheres, dim3(ceil_div(d.n_sph, BLOCK)), dim3(BLOCK), 0, stream, raw_sph, d.sph_nb, sph);
     if (d.n_ell) hipLaunchKernelGGL(k_prep_ellipsoids, dim3(ceil_div(d.n_ell, BLOCK)), dim3(BLOCK), 0, stream, raw_inv, raw_fwd, d.ell_nb, ell);
     if (d.n_ell && desc->n_point_lights)
         hipLaunchKernelGGL(k_prep_ellipsoid_lights, dim3(ceil_div(d.n_ell, BLOCK)), dim3(BLOCK), 0, stream, ell, d.n_ell, raw_pl, static_cast<uint32_t>(desc->n_point_lights), ell_light);
-    d.tri = tri; d.sph = sph; d.ell = ell; d.ell_light = ell_light;
+    d.tri = tri; d.trif = trif; d.sph = sph; d.ell = ell; d.ell_light = ell_light;
 
     // light table: the directional light first (ray_tracing.cpp:687), then the point lights in file order (:704)
     std::vector<float> lights;
