@@ -12,7 +12,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librt_amd.so")
+# RT_AMD_LIB: alternative build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "lib", "librt_amd.so")
 _lib = None
 
 

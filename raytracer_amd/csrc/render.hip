@@ -64,7 +64,8 @@ constexpr uint32_t SAMPLES_PER_TILE = RT_TILE * RT_TILE * RT_SAMPLES_PER_PIXEL; 
 // smallest (distance, lane, batch), not the smallest index (ray_tracing.cpp:489-516).
 struct DevScene {
     const float4* tri;   // 4 x float4 per triangle: (a, n.x) (a_to_b, n.y) (a_to_c, n.z) (n.n, 0, 0, 0)
-    const float4* trif;  // pre-test records, 4 x float4 per triangle: (n, G) (a, H) (w1, 0) (w2, 0), see pretest_rejects
+    const float4* trif;  // pre-test records, 4 x float4 per triangle: (n, -2G) (a, -2H) (w1, 0) (w2, 0), see pretest_rejects
+    const float4* trio;  // pre-test records for rays from the camera eye, see pretest_rejects_from
     const float4* sph;   // (centre, radius)
     const float4* ell;   // 6 x float4: rows of the inverse transform, rows of the transform
     const float4* ell_light;  // [point light][ellipsoid]: inverse transform applied to the light position
@@ -212,22 +213,24 @@ DEV float hit_triangle(V3 o, V3 d, float4 t0, float4 t1, float4 t2, float nn) {
 }
 
 // Conservative pre-test of one ray against one triangle: returns true only when the full
-// test above is certain to return FLT_MAX or a distance outside (t_min, t_max).  It is not part
-// of the reference; it exists because the full test spends most of its time in three IEEE
-// divisions, while almost every ray misses almost every triangle.
+// test above is certain to return FLT_MAX.  It is not part of the reference; it exists because
+// the full test spends most of its time in three IEEE divisions (about 17 issue slots each on
+// gfx950) while almost every ray misses almost every triangle.
 //
 // With n, a and nn as in the full test, w1 = (n x a_to_b)/nn and w2 = (a_to_c x n)/nn, the
 // full test's barycentrics are alpha = w1.(p - a), beta = w2.(p - a) in real arithmetic.
-// Here t1 = ((a-o).n) * rcp(d.n) (same dot products as the full test, reciprocal instead of a
-// division), ap = t1*d - (a-o), alpha1 = w1.ap, beta1 = w2.ap.  A rounding analysis of both
-// evaluation orders ("Pre-test margin") bounds |alpha1 - alpha| and |beta1 - beta| by
+// Here t1 = ((a-o).n) * rcp(d.n) (the same two dot products, bit for bit, as the full test,
+// and a reciprocal instead of a division), ap = t1*d - (a-o), alpha1 = w1.ap, beta1 = w2.ap.
+// A rounding analysis of both evaluation orders ("Pre-test margin") bounds
+// |alpha1 - alpha| and |beta1 - beta| by
 //     m = 130 eps Q (|o|_inf + |t| + |a|_inf) + eps,  Q = |n|_inf max(|a_to_b|_inf, |a_to_c|_inf)/nn,
-// eps = 2^-24.  The record carries G = 2^-16 Q (about twice 130 eps Q) and H = G |a|_inf + 2^-22,
-// so m <= G (|t1| + |o|_inf) + H, and a ray is rejected only if
-//     min(alpha1, beta1, 1 - alpha1 - beta1) < -2m,  or t1 outside [t_min, t_max],
-// with t_min, t_max widened by the caller by more than the reciprocal's error.  Any NaN or
-// infinity makes the comparisons false, i.e. "not rejected", and the full test decides.
-DEV bool pretest_rejects(V3 o, V3 d, float o_max, float t_min, float t_max, float4 f0, float4 f1, float4 f2, float4 f3) {
+// eps = 2^-24.  With G = 2^-16 Q (about twice 130 eps Q) and H = G |a|_inf + 2^-22,
+// m <= G (|t1| + |o|_inf) + H, and a ray is rejected only if
+//     min(alpha1, beta1, 1 - alpha1 - beta1) < -2m.
+// The record stores -2G and -2H.  The distance itself is not tested here: the few triangles a
+// ray's line crosses behind its origin or beyond the current best go to the full test, which
+// rejects them.  Any NaN or infinity makes the comparison false ("not rejected").
+DEV bool pretest_rejects(V3 o, V3 d, float o_max, float4 f0, float4 f1, float4 f2, float4 f3) {
     const V3 n = xyz(f0), a = xyz(f1), w1 = xyz(f2), w2 = xyz(f3);
     const float dn = vdot(d, n);
     const V3 ao = sub(a, o);
@@ -238,8 +241,22 @@ DEV bool pretest_rejects(V3 o, V3 d, float o_max, float t_min, float t_max, floa
     const float beta = vdot(ap, w2);
     const float rest = 1.0f - (alpha + beta);
     const float u = __builtin_fminf(__builtin_fminf(alpha, beta), rest);
-    const float m2 = fma_(f0.w, __builtin_fabsf(t1) + o_max, f1.w);   // m
-    return (u < -2.0f * m2) | (t1 < t_min) | (t1 > t_max);
+    return u < fma_(f0.w, __builtin_fabsf(t1) + o_max, f1.w);
+}
+
+// The same pre-test for rays that all start at one point X (the camera eye): a - X, (a - X).n
+// and the |X|_inf part of the margin are per-triangle constants, prepared by k_prep_origin.
+// Record: (n, -2G) (a - X, -2(G |X|_inf + H)) (w1, (a - X).n) (w2, 0).
+DEV bool pretest_rejects_from(V3 d, float4 f0, float4 f1, float4 f2, float4 f3) {
+    const V3 n = xyz(f0), ao = xyz(f1), w1 = xyz(f2), w2 = xyz(f3);
+    const float dn = vdot(d, n);
+    const float t1 = f2.w * __builtin_amdgcn_rcpf(dn);
+    const V3 ap{fma_(t1, d.x, -ao.x), fma_(t1, d.y, -ao.y), fma_(t1, d.z, -ao.z)};
+    const float alpha = vdot(ap, w1);
+    const float beta = vdot(ap, w2);
+    const float rest = 1.0f - (alpha + beta);
+    const float u = __builtin_fminf(__builtin_fminf(alpha, beta), rest);
+    return u < fma_(f0.w, __builtin_fabsf(t1), f1.w);
 }
 
 // ray_tracing.cpp:169-206; the far root is replaced by the near one at :202 and that is kept
@@ -366,10 +383,29 @@ __global__ void __launch_bounds__(BLOCK) k_prep_triangles(const float* __restric
     const float G = 1.0001f * (1.0f / 65536.0f) * (n_max * e_max * inv_nn);
     const float H = 1.0001f * (G * a_max) + (1.0f / 4194304.0f);
     float4* q = outf + static_cast<size_t>(k) * 4;
-    q[0] = make_float4(n.x, n.y, n.z, G);
-    q[1] = make_float4(a.x, a.y, a.z, H);
+    q[0] = make_float4(n.x, n.y, n.z, -2.0f * G);
+    q[1] = make_float4(a.x, a.y, a.z, -2.0f * H);
     q[2] = make_float4(w1.x, w1.y, w1.z, 0.0f);
     q[3] = make_float4(w2.x, w2.y, w2.z, 0.0f);
+}
+
+// pre-test records for rays that all start at X (pretest_rejects_from)
+__global__ void __launch_bounds__(BLOCK) k_prep_origin(const float4* __restrict__ tri, const float4* __restrict__ trif, uint32_t n_tri,
+                                                       float x, float y, float z, float4* __restrict__ out) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n_tri) return;
+    const float4 t0 = tri[static_cast<size_t>(k) * 4];
+    const float4* f = trif + static_cast<size_t>(k) * 4;
+    const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
+    const V3 n = xyz(f0);
+    const V3 ao = sub(xyz(t0), V3{x, y, z});          // the full test's a - o
+    const float num = vdot(ao, n);                     // and its (a - o).n
+    const float x_max = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    float4* q = out + static_cast<size_t>(k) * 4;
+    q[0] = f0;
+    q[1] = make_float4(ao.x, ao.y, ao.z, 1.0001f * (f0.w * x_max) + f1.w);   // both terms are negative
+    q[2] = make_float4(f2.x, f2.y, f2.z, num);
+    q[3] = f3;
 }
 
 __global__ void __launch_bounds__(BLOCK) k_prep_spheres(const float* __restrict__ sph8, uint32_t nb, float4* __restrict__ out) {
@@ -470,8 +506,10 @@ DEV void stage_tile(float4* lds, const float4* __restrict__ src, uint32_t first,
     for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) lds[i] = g[i];
 }
 
-template <int R, bool FILTER>
+// MODE 0: every triangle through the full test; 1: pre-test first; 2: pre-test for rays from the eye (bounce 0)
+template <int R, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_closest(DevScene sc, State st, uint32_t bounce) {
+    constexpr bool FILTER = MODE != 0;
     __shared__ float4 lds[TILE_PRIMS * 6];
     __shared__ uint32_t lds_scan[8];
     const uint32_t n_rays = st.counts[bounce];
@@ -493,14 +531,14 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DevScene sc, State st, uint32
 
     // ---- triangles ----
     float tri_t[R]; uint32_t tri_k[R];
-    float tri_t_hi[R], o_max[R];   // pre-test only: widened current best, |o|_inf
+    float o_max[R];   // pre-test only: |o|_inf
     unsigned long long n_full = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        tri_t[r] = FLT_MAX; tri_k[r] = 0xFFFFFFFFu; tri_t_hi[r] = __builtin_inff();
+        tri_t[r] = FLT_MAX; tri_k[r] = 0xFFFFFFFFu;
         o_max[r] = fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z)));
     }
-    const float4* __restrict__ tri_stream = FILTER ? sc.trif : sc.tri;
+    const float4* __restrict__ tri_stream = MODE == 2 ? sc.trio : (MODE == 1 ? sc.trif : sc.tri);
     for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
         __syncthreads();
@@ -512,7 +550,8 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DevScene sc, State st, uint32
             if (FILTER) {
                 bool survive = false;
 #pragma unroll
-                for (int r = 0; r < R; ++r) survive |= !pretest_rejects(o[r], d[r], o_max[r], TOL * 0.99999f, tri_t_hi[r], t0, t1, t2, t3);
+                for (int r = 0; r < R; ++r)
+                    survive |= MODE == 2 ? !pretest_rejects_from(d[r], t0, t1, t2, t3) : !pretest_rejects(o[r], d[r], o_max[r], t0, t1, t2, t3);
                 if (__any(survive)) {
                     // some lane may hit: the whole wave runs the full test on the full record
                     const float4* __restrict__ rec = sc.tri + static_cast<size_t>(first + k) * 4;
@@ -520,7 +559,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DevScene sc, State st, uint32
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const float t = hit_triangle(o[r], d[r], e0, e1, e2, e3.x);
-                        if (t < tri_t[r]) { tri_t[r] = t; tri_k[r] = first + k; tri_t_hi[r] = t * 1.000001f; }
+                        if (t < tri_t[r]) { tri_t[r] = t; tri_k[r] = first + k; }
                     }
                     n_full += R;
                 }
@@ -644,7 +683,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DevScene sc, State st, uint32
 // k_shadow: any-hit of every hit point toward light (first_light + blockIdx.y)
 // ------------------------------------------------------------------------------------------
 template <int R, bool FILTER>
-__global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, State st, uint32_t bounce, uint32_t first_light) {
+__global__ void __launch_bounds__(BLOCK, 6) k_shadow(DevScene sc, State st, uint32_t bounce, uint32_t first_light) {
     __shared__ float4 lds[TILE_PRIMS * 4];
     const uint32_t n_rays = st.counts[bounce + 1];
     const uint32_t base = blockIdx.x * (BLOCK * R);
@@ -659,7 +698,12 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, State st, uint32_
     bool valid[R], blocked[R];
     V3 o[R], d[R];
     float limit[R];
-    uint32_t tests[R][3];
+    // tests actually spent on undecided rays, per kind; wave-uniform (kept in scalar registers)
+    unsigned long long wave_tests[3] = {0, 0, 0};
+    auto count_tests = [&](int kind, uint32_t count) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) wave_tests[kind] += static_cast<unsigned long long>(count) * __popcll(__ballot(valid[r] && !blocked[r]));
+    };
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t i = base + r * BLOCK + threadIdx.x;
@@ -678,7 +722,6 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, State st, uint32_
             limit[r] = FLT_MAX;
         }
         blocked[r] = false;
-        tests[r][0] = tests[r][1] = tests[r][2] = 0;
     }
 
     auto wave_done = [&]() {
@@ -689,13 +732,10 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, State st, uint32_
     };
     bool done = wave_done();
 
-    float o_max[R], limit_hi[R];
+    float o_max[R];
     unsigned long long n_full = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        o_max[r] = fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z)));
-        limit_hi[r] = limit[r] * 1.000001f;   // FLT_MAX becomes +inf: nothing is rejected for being too far
-    }
+    for (int r = 0; r < R; ++r) o_max[r] = fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z)));
     const float4* __restrict__ tri_stream = FILTER ? sc.trif : sc.tri;
     for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
@@ -703,15 +743,14 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, State st, uint32_
         stage_tile<4>(lds, tri_stream, first, count);
         __syncthreads();
         if (!done) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) if (valid[r] && !blocked[r]) tests[r][0] += count;
+            count_tests(0, count);
 #pragma unroll 2
             for (uint32_t k = 0; k < count; ++k) {
                 const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
                 if (FILTER) {
                     bool survive = false;
 #pragma unroll
-                    for (int r = 0; r < R; ++r) survive |= !pretest_rejects(o[r], d[r], o_max[r], TOL * 0.99999f, limit_hi[r], t0, t1, t2, t3);
+                    for (int r = 0; r < R; ++r) survive |= !pretest_rejects(o[r], d[r], o_max[r], t0, t1, t2, t3);
                     if (__any(survive)) {
                         const float4* __restrict__ rec = sc.tri + static_cast<size_t>(first + k) * 4;
                         const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3];
@@ -733,8 +772,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, State st, uint32_
         stage_tile<1>(lds, sc.sph, first, count);
         __syncthreads();
         if (!done) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) if (valid[r] && !blocked[r]) tests[r][1] += count;
+            count_tests(1, count);
 #pragma unroll 2
             for (uint32_t k = 0; k < count; ++k) {
                 const float4 s = lds[k];
@@ -756,8 +794,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, State st, uint32_
         }
         __syncthreads();
         if (!done) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) if (valid[r] && !blocked[r]) tests[r][2] += count;
+            count_tests(2, count);
             for (uint32_t k = 0; k < count; ++k) {
                 const float4 i0 = lds[k * 4], i1 = lds[k * 4 + 1], i2 = lds[k * 4 + 2], l2 = lds[k * 4 + 3];
 #pragma unroll
@@ -767,20 +804,21 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, State st, uint32_
         }
     }
 
-    unsigned long long n_valid = 0, n_blocked = 0, t_tri = 0, t_sph = 0, t_ell = 0;
+    unsigned long long n_valid = 0, n_blocked = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (valid[r]) {
             n_valid++;
             if (blocked[r]) { n_blocked++; atomicOr(&st.blocked[slot[r]], 1u << blockIdx.y); }
-            t_tri += tests[r][0]; t_sph += tests[r][1]; t_ell += tests[r][2];
         }
     }
     block_add_stat(&st.stats[ST_SHADOW_RAYS], n_valid);
     block_add_stat(&st.stats[ST_SHADOW_BLOCKED], n_blocked);
-    block_add_stat(&st.stats[ST_SHADOW_TESTS_TRI], t_tri);
-    block_add_stat(&st.stats[ST_SHADOW_TESTS_SPH], t_sph);
-    block_add_stat(&st.stats[ST_SHADOW_TESTS_ELL], t_ell);
+    if ((threadIdx.x & 63u) == 0) {
+        if (wave_tests[0]) atomicAdd(&st.stats[ST_SHADOW_TESTS_TRI], wave_tests[0]);
+        if (wave_tests[1]) atomicAdd(&st.stats[ST_SHADOW_TESTS_SPH], wave_tests[1]);
+        if (wave_tests[2]) atomicAdd(&st.stats[ST_SHADOW_TESTS_ELL], wave_tests[2]);
+    }
     if (FILTER) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
 }
 
@@ -902,8 +940,11 @@ struct Library {
 };
 Library g_lib;
 
-constexpr int RAYS_PER_LANE = 2;
-constexpr uint32_t DEFAULT_CHUNK_TILES = 2048;   // 8.4 M samples
+#ifndef RT_RAYS_PER_LANE
+#define RT_RAYS_PER_LANE 2
+#endif
+constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;
+constexpr uint32_t DEFAULT_CHUNK_TILES = 8192;   // 33.5 M samples, 3.1 GB of ray state
 constexpr uint32_t MAX_BOUNCES = 62;
 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
@@ -930,6 +971,10 @@ uint32_t rank_tiles(const rt_render_params& p) {
 struct rt_scene {
     DevScene dev;
     std::vector<void*> allocations;
+    // pre-test records for rays from the eye, rebuilt when the eye moves (one render at a time per scene)
+    mutable float4* eye_records = nullptr;
+    mutable float eye[3] = {0, 0, 0};
+    mutable bool eye_valid = false;
 };
 
 namespace {
@@ -999,7 +1044,18 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     const size_t chunk_samples = static_cast<size_t>(chunk_tiles) * SAMPLES_PER_TILE;
     if (int rc = ensure_state(chunk_samples)) return rc;
 
-    const DevScene& sc = scene->dev;
+    DevScene sc = scene->dev;
+    hipStream_t stream = g_lib.stream;
+    if (sc.n_tri && scene->eye_records) {
+        if (!scene->eye_valid || std::memcmp(scene->eye, cam->eye, sizeof scene->eye) != 0) {
+            hipLaunchKernelGGL(k_prep_origin, dim3(ceil_div(sc.n_tri, BLOCK)), dim3(BLOCK), 0, stream, sc.tri, sc.trif, sc.n_tri,
+                               cam->eye[0], cam->eye[1], cam->eye[2], scene->eye_records);
+            HIP_TRY(hipGetLastError());
+            std::memcpy(scene->eye, cam->eye, sizeof scene->eye);
+            scene->eye_valid = true;
+        }
+        sc.trio = scene->eye_records;
+    }
     Frame f;
     std::memcpy(f.eye, cam->eye, sizeof f.eye);
     std::memcpy(f.bi, cam->basis_i, sizeof f.bi);
@@ -1012,7 +1068,6 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     f.tiles_x = rect.tiles_x; f.tile_rank = prm->tile_rank; f.tile_world = world;
 
     State st = make_state(chunk_samples, ids_dev != nullptr);
-    hipStream_t stream = g_lib.stream;
     HIP_TRY(hipMemsetAsync(g_lib.stats, 0, ST_COUNT * sizeof(unsigned long long), stream));
 
     Timer timer_storage;
@@ -1030,8 +1085,9 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         const uint32_t scan_blocks = ceil_div(n_samples, BLOCK * RAYS_PER_LANE);
         for (uint32_t b = 0; b < depth; ++b) {
             timed(timer, 0, [&] {
-                if (filter) hipLaunchKernelGGL((k_closest<RAYS_PER_LANE, true>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-                else hipLaunchKernelGGL((k_closest<RAYS_PER_LANE, false>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+                if (!filter) hipLaunchKernelGGL((k_closest<RAYS_PER_LANE, 0>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+                else if (b == 0 && sc.trio) hipLaunchKernelGGL((k_closest<RAYS_PER_LANE, 2>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+                else hipLaunchKernelGGL((k_closest<RAYS_PER_LANE, 1>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
             });
             if (sc.n_lights == 0) {
                 hipLaunchKernelGGL(k_shade, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, sc, st, b, 0u, 0u, 1u);
@@ -1157,6 +1213,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     float4 *tri, *trif, *sph, *ell, *ell_light;
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &tri))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &trif))) return fail(rc);
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &s->eye_records))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, d.n_sph, &sph))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * 6, &ell))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * desc->n_point_lights, &ell_light))) return fail(rc);
