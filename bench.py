@@ -75,7 +75,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from raytracer_amd import abi, api
+    from raytracer_amd import abi, api, distributed
 
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -89,12 +89,10 @@ def main():
     cam = fi.camera()
     scene = api.Scene(fi.scene_desc)
     prm = fi.params(max_bounce_count=depth, tile_rank=rank, tile_world=world)
-    total_tiles = api.total_tile_count(prm)
-    stride = (total_tiles + world - 1) // world
-    my_tiles = api.rank_tile_count(prm)
+    stride = distributed.stride_tiles(prm, world)      # tiles per rank in the gathered buffer
+    assert api.rank_tile_count(prm) == len(distributed.rank_tiles(prm, rank, world)) <= stride
 
     tiles = torch.zeros(stride * TILE_BYTES, dtype=torch.uint8, device=device)
-    gathered = torch.zeros(world * stride * TILE_BYTES, dtype=torch.uint8, device=device) if world > 1 else tiles
     frame = torch.zeros(fi.height * fi.width * 3, dtype=torch.uint8, device=device) if rank == 0 else None
 
     def barrier():
@@ -104,8 +102,8 @@ def main():
 
     def step():
         st = scene.render_tiles_device(cam, prm, tiles.data_ptr(), want_stats=True)   # returns with its stream idle
+        gathered = distributed.all_gather_tiles(tiles, world)   # RCCL over xGMI: the framebuffer exchange
         if world > 1:
-            dist.all_gather_into_tensor(gathered, tiles)     # RCCL over xGMI: the framebuffer exchange
             torch.cuda.synchronize()
         if rank == 0:
             api.assemble_tiles_device(gathered.data_ptr(), stride, prm, frame.data_ptr())

@@ -1,0 +1,148 @@
+"""CPU oracle (oracle/rt_oracle.cpp) against known answers captured from the unmodified reference.
+
+Two sources: the bit patterns tabulated while surveying the reference (fp_pow table, scene1 camera
+basis and primary rays), and tests/golden/known_answers.npz (random inputs -> reference outputs,
+written by tests/golden/make_golden.py).  Everything is compared bit for bit.
+"""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import checkers
+from conftest import ROOT
+from raytracer_amd import abi
+
+KA = np.load(os.path.join(ROOT, "tests", "golden", "known_answers.npz"))
+
+
+def bits(x):
+    return struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+def same_bits(a, b):
+    a = np.asarray(a, np.float32).view(np.uint32)
+    b = np.asarray(b, np.float32).view(np.uint32)
+    return np.array_equal(a, b)
+
+
+# fp_pow(x, y) -> IEEE bits, from the reference built with clang -ffp-contract=on
+POW_TABLE = [
+    (1.0, 1.0, 0x3F7FFC7E), (1.0, 20.0, 0x3F7FFC7E), (1.0, 40.0, 0x3F7FFC7E),
+    (0.999, 20.0, 0x3F7AF77D),
+    (0.9, 1.0, 0x3F666A39), (0.9, 20.0, 0x3DF904B8), (0.9, 40.0, 0x3C723C25),
+    (0.5, 1.0, 0x3EFFF992), (0.5, 20.0, 0x35800253), (0.5, 40.0, 0x2B800829),
+    (0.25, 20.0, 0x2B80026A),
+    (0.1, 1.0, 0x3DCCCC23), (0.1, 20.0, 0x1E3CE11E), (0.1, 40.0, 0x00000000),
+    (1e-3, 1.0, 0x3A8311F3), (1e-30, 1.0, 0x0DA241FF),
+    (0.0, 20.0, 0x00000000), (0.5, 0.0, 0x3F800000), (0.0, 0.0, 0x3F800000),
+]
+
+
+@pytest.mark.parametrize("x,y,expect", POW_TABLE)
+def test_fp_pow_table(oracle, x, y, expect):
+    assert bits(oracle.rto_fp_pow(x, y)) == expect
+
+
+def test_fp_pow_random(oracle):
+    out = np.array([oracle.rto_fp_pow(float(a), float(b)) for a, b in zip(KA["pow_x"], KA["pow_y"])], np.float32)
+    assert same_bits(out, KA["pow_out"])
+
+
+def test_fp_pow_never_reaches_one_unless_exponent_is_zero(oracle):
+    assert oracle.rto_fp_pow(1.0, 5.0) < 1.0
+    assert oracle.rto_fp_pow(1.0, 1e-45) == 1.0   # subnormal exponent counts as zero
+
+
+def test_fp_min_max_return_second_operand_on_nan(oracle):
+    mm = KA["mm_in"]
+    mn = np.array([[oracle.rto_fp_min(float(a), float(b)) for b in mm] for a in mm], np.float32)
+    mx = np.array([[oracle.rto_fp_max(float(a), float(b)) for b in mm] for a in mm], np.float32)
+    assert same_bits(mn, KA["min_out"])
+    assert same_bits(mx, KA["max_out"])
+    nan = float("nan")
+    assert oracle.rto_fp_max(nan, 0.0) == 0.0 and np.isnan(oracle.rto_fp_max(0.0, nan))
+    assert oracle.rto_fp_min(nan, 0.0) == 0.0 and np.isnan(oracle.rto_fp_min(0.0, nan))
+    assert bits(oracle.rto_fp_max(-0.0, 0.0)) == 0x00000000 and bits(oracle.rto_fp_max(0.0, -0.0)) == 0x80000000
+
+
+def _scene1_camera(oracle):
+    cam11 = (C.c_float * 11)(-4, -4, 4, 1, 0, 0, 0, 1, 0, 640 * 30.0 / 480, 30.0)
+    cam = abi.CameraDesc()
+    oracle.rto_camera_setup(C.byref(cam11), C.byref(cam))
+    return cam
+
+
+def test_scene1_camera_basis_bits(oracle):
+    cam = _scene1_camera(oracle)
+    assert [bits(v) for v in cam.basis_i] == [0xBF1FEC04, 0x00000000, 0xBF47E704]
+    assert [bits(v) for v in cam.basis_j] == [0xBED3D25F, 0x3F591E08, 0x3EA97519]
+    assert [bits(v) for v in cam.basis_k] == [0x3F298A46, 0x3F07A1D2, 0xBF07A1D2]
+    assert [bits(v) for v in cam.half_world] == [0x3EBA5A4F, 0x3E8930A3]
+
+
+def test_scene1_primary_ray_bits(oracle):
+    cam = _scene1_camera(oracle)
+    out = (C.c_float * 3)()
+    oracle.rto_ray_direction_through_pixel(0, 0, 2.0, 2.0, C.byref(cam), 320.0, 240.0, C.byref(out))
+    assert [bits(v) for v in out] == [0x3E987578, 0x3F305FE8, 0xBF292A70]
+    oracle.rto_ray_direction_through_pixel(320, 240, 2.75, 2.75, C.byref(cam), 320.0, 240.0, C.byref(out))
+    assert [bits(v) for v in out] == [0x3F2A5D29, 0x3F06F6D7, 0xBF074404]
+
+
+@pytest.mark.parametrize("name", ["scene1", "scene6"])
+def test_primary_rays_random(oracle, name):
+    import json
+    parsed = json.load(open(os.path.join(ROOT, "tests", "golden", "parsed.json")))
+    cam = abi.CameraDesc.from_buffer_copy(bytes.fromhex(parsed[name]["camera_desc_hex"]))
+    px, py, s, want = KA["ray_%s_px" % name], KA["ray_%s_py" % name], KA["ray_%s_sample" % name], KA["ray_%s_dir" % name]
+    got = np.zeros_like(want)
+    out = (C.c_float * 3)()
+    for i in range(len(px)):
+        # sample offsets are 2.0, 2.25, 2.5, 2.75 (0.5 * SQRT_SAMPLES_PER_PIXEL, not 0.5 / it)
+        oracle.rto_ray_direction_through_pixel(int(px[i]), int(py[i]), float(s[i] % 4) * 0.25 + 2.0, float(s[i] // 4) * 0.25 + 2.0,
+                                               C.byref(cam), 320.0, 240.0, C.byref(out))
+        got[i] = list(out)
+    assert same_bits(got, want)
+
+
+def test_aabb_slab_test(oracle):
+    o, d, box, want = KA["aabb_o"], KA["aabb_d"], KA["aabb_box"], KA["aabb_out"]
+    got = np.zeros_like(want)
+    out = (C.c_float * 2)()
+    cbox = (C.c_float * 6)(*box)
+    for i in range(len(o)):
+        oracle.rto_intersect_aabb(C.byref(checkers.vec3(o[i])), C.byref(checkers.vec3(d[i])), C.byref(cbox), C.byref(out))
+        got[i] = list(out)
+    assert same_bits(got, want)
+
+
+def test_triangle8_batches(oracle):
+    t8, o, d, want = KA["tri8"], KA["tri_o"], KA["tri_d"], KA["tri_out"]
+    got = np.zeros_like(want)
+    out = (C.c_float * 8)()
+    for b in range(len(t8)):
+        rec = np.ascontiguousarray(t8[b])
+        oracle.rto_intersect_triangle8(C.byref(checkers.vec3(o[b])), C.byref(checkers.vec3(d[b])), rec.ctypes.data, C.byref(out))
+        got[b] = list(out)
+    assert same_bits(got, want)
+    flt_max = np.float32(np.finfo(np.float32).max)
+    assert (want == flt_max).any() and (want != flt_max).any()       # the fixture has hits and misses
+    padded = t8[::4, :].reshape(-1, 9, 8)[:, :, 5:]                  # zero padding lanes never hit
+    assert not padded.any() and (want[::4, 5:] == flt_max).all()
+
+
+def test_sphere8_batches_keep_the_near_root_bug(oracle):
+    s8, o, d, want = KA["sph8"], KA["sph_o"], KA["sph_d"], KA["sph_out"]
+    got = np.zeros_like(want)
+    out = (C.c_float * 8)()
+    for b in range(len(s8)):
+        rec = np.ascontiguousarray(s8[b])
+        oracle.rto_intersect_sphere8(C.byref(checkers.vec3(o[b])), C.byref(checkers.vec3(d[b])), rec.ctypes.data, C.byref(out))
+        got[b] = list(out)
+    assert same_bits(got, want)
+    # origin inside a sphere: the reference returns the near root, which is below the tolerance (often negative)
+    inside = want[0::3][np.arange(len(want[0::3])), (np.arange(len(want))[0::3]) % 8]
+    assert (inside < 1e-4).any()
