@@ -64,8 +64,8 @@ constexpr uint32_t SAMPLES_PER_TILE = RT_TILE * RT_TILE * RT_SAMPLES_PER_PIXEL; 
 // smallest (distance, lane, batch), not the smallest index (ray_tracing.cpp:489-516).
 struct DevScene {
     const float4* tri;   // 4 x float4 per triangle: (a, n.x) (a_to_b, n.y) (a_to_c, n.z) (n.n, 0, 0, 0)
-    const float4* trif;  // pre-test records, 4 x float4 per triangle: (n, -2G) (a, -2H) (w1, 0) (w2, 0), see pretest_rejects
-    const float4* trio;  // pre-test records for rays from the camera eye, see pretest_rejects_from
+    const float4* trif;  // pre-test records, 4 x float4 per triangle, see pretest_stage1
+    const float4* trio;  // pre-test records for rays from the camera eye, see pretest_from_stage1
     const float4* sph;   // (centre, radius)
     const float4* ell;   // 6 x float4: rows of the inverse transform, rows of the transform
     const float4* ell_light;  // [point light][ellipsoid]: inverse transform applied to the light position
@@ -212,10 +212,10 @@ DEV float hit_triangle(V3 o, V3 d, float4 t0, float4 t1, float4 t2, float nn) {
     return (parallel | behind | outside) ? FLT_MAX : t;
 }
 
-// Conservative pre-test of one ray against one triangle: returns true only when the full
-// test above is certain to return FLT_MAX.  It is not part of the reference; it exists because
-// the full test spends most of its time in three IEEE divisions (about 17 issue slots each on
-// gfx950) while almost every ray misses almost every triangle.
+// Conservative pre-test of one ray against one triangle, in two stages.  A stage returns
+// false only when the full test above is certain to return FLT_MAX.  It is not part of the
+// reference; it exists because the full test spends most of its time in three IEEE divisions
+// (about 17 issue slots each on gfx950) while almost every ray misses almost every triangle.
 //
 // With n, a and nn as in the full test, w1 = (n x a_to_b)/nn and w2 = (a_to_c x n)/nn, the
 // full test's barycentrics are alpha = w1.(p - a), beta = w2.(p - a) in real arithmetic.
@@ -223,40 +223,52 @@ DEV float hit_triangle(V3 o, V3 d, float4 t0, float4 t1, float4 t2, float nn) {
 // and a reciprocal instead of a division), ap = t1*d - (a-o), alpha1 = w1.ap, beta1 = w2.ap.
 // A rounding analysis of both evaluation orders ("Pre-test margin") bounds
 // |alpha1 - alpha| and |beta1 - beta| by
-//     m = 130 eps Q (|o|_inf + |t| + |a|_inf) + eps,  Q = |n|_inf max(|a_to_b|_inf, |a_to_c|_inf)/nn,
-// eps = 2^-24.  With G = 2^-16 Q (about twice 130 eps Q) and H = G |a|_inf + 2^-22,
-// m <= G (|t1| + |o|_inf) + H, and a ray is rejected only if
-//     min(alpha1, beta1, 1 - alpha1 - beta1) < -2m.
-// The record stores -2G and -2H.  The distance itself is not tested here: the few triangles a
-// ray's line crosses behind its origin or beyond the current best go to the full test, which
-// rejects them.  Any NaN or infinity makes the comparison false ("not rejected").
-DEV bool pretest_rejects(V3 o, V3 d, float o_max, float4 f0, float4 f1, float4 f2, float4 f3) {
-    const V3 n = xyz(f0), a = xyz(f1), w1 = xyz(f2), w2 = xyz(f3);
+//     m = 132 eps Q (|o|_inf + |t| + |a|_inf) + eps,  Q = |n|_inf max(|a_to_b|_inf, |a_to_c|_inf)/nn,
+// eps = 2^-24.  With G = 2^-15 Q (about four times 132 eps Q) and H = G |a|_inf + 2^-22,
+// m <= G (|t1| + |o|_inf) + H.  Stage 1 keeps a ray when alpha1 is within [-2m, 1 + 2m], stage 2
+// when min(alpha1, beta1, 1 - alpha1 - beta1) >= -2m.  The record stores Ga = 2G and
+// Ha = 2H + 0.5, so that thr = Ga (|t1| + |o|_inf) + Ha = 0.5 + 2m.
+// The distance itself is not tested: the few triangles a ray's line crosses behind its origin or
+// beyond the current best go to the full test, which rejects them.  Any NaN or infinity makes
+// the comparisons false, which keeps the ray.
+// Record: (n, Ga) (a, Ha) (w1, 0) (w2, 0).
+struct Pre { V3 ap; float alpha, thr; };
+DEV bool pretest_stage1(V3 o, V3 d, float o_max, float4 f0, float4 f1, float4 f2, Pre& s) {
+    const V3 n = xyz(f0), a = xyz(f1), w1 = xyz(f2);
     const float dn = vdot(d, n);
     const V3 ao = sub(a, o);
     const float num = vdot(ao, n);
     const float t1 = num * __builtin_amdgcn_rcpf(dn);
-    const V3 ap{fma_(t1, d.x, -ao.x), fma_(t1, d.y, -ao.y), fma_(t1, d.z, -ao.z)};
-    const float alpha = vdot(ap, w1);
-    const float beta = vdot(ap, w2);
-    const float rest = 1.0f - (alpha + beta);
-    const float u = __builtin_fminf(__builtin_fminf(alpha, beta), rest);
-    return u < fma_(f0.w, __builtin_fabsf(t1) + o_max, f1.w);
+    s.ap = V3{fma_(t1, d.x, -ao.x), fma_(t1, d.y, -ao.y), fma_(t1, d.z, -ao.z)};
+    s.alpha = vdot(s.ap, w1);
+    s.thr = fma_(f0.w, __builtin_fabsf(t1) + o_max, f1.w);
+    return !(__builtin_fabsf(s.alpha - 0.5f) > s.thr);
+}
+DEV bool pretest_stage2(const Pre& s, float4 f3) {
+    const float beta = vdot(s.ap, xyz(f3));
+    const float rest = 1.0f - (s.alpha + beta);
+    const float u = __builtin_fminf(__builtin_fminf(s.alpha, beta), rest);
+    return !(u < 0.5f - s.thr);
 }
 
-// The same pre-test for rays that all start at one point X (the camera eye): a - X, (a - X).n
-// and the |X|_inf part of the margin are per-triangle constants, prepared by k_prep_origin.
-// Record: (n, -2G) (a - X, -2(G |X|_inf + H)) (w1, (a - X).n) (w2, 0).
-DEV bool pretest_rejects_from(V3 d, float4 f0, float4 f1, float4 f2, float4 f3) {
-    const V3 n = xyz(f0), ao = xyz(f1), w1 = xyz(f2), w2 = xyz(f3);
-    const float dn = vdot(d, n);
-    const float t1 = f2.w * __builtin_amdgcn_rcpf(dn);
-    const V3 ap{fma_(t1, d.x, -ao.x), fma_(t1, d.y, -ao.y), fma_(t1, d.z, -ao.z)};
-    const float alpha = vdot(ap, w1);
-    const float beta = vdot(ap, w2);
-    const float rest = 1.0f - (alpha + beta);
-    const float u = __builtin_fminf(__builtin_fminf(alpha, beta), rest);
-    return u < fma_(f0.w, __builtin_fabsf(t1), f1.w);
+// The same pre-test for rays that all start at one point X (the camera eye): (a - X).n,
+// c1 = w1.(a - X), c2 = w2.(a - X) and the |X|_inf part of the margin are per-triangle
+// constants prepared by k_prep_origin, and alpha1 = t1 (w1.d) - c1, beta1 = t1 (w2.d) - c2
+// (rounding bound 132 eps Q (...) as above).
+// Record: (n, (a - X).n) (w1, c1) (w2, c2) (Ga, Ga |X|_inf + Ha, 0, 0).
+struct PreFrom { float t1, alpha, thr; };
+DEV bool pretest_from_stage1(V3 d, float4 f0, float4 f1, float4 f3, PreFrom& s) {
+    const float dn = vdot(d, xyz(f0));
+    s.t1 = f0.w * __builtin_amdgcn_rcpf(dn);
+    s.alpha = fma_(s.t1, vdot(d, xyz(f1)), -f1.w);
+    s.thr = fma_(f3.x, __builtin_fabsf(s.t1), f3.y);
+    return !(__builtin_fabsf(s.alpha - 0.5f) > s.thr);
+}
+DEV bool pretest_from_stage2(V3 d, const PreFrom& s, float4 f2) {
+    const float beta = fma_(s.t1, vdot(d, xyz(f2)), -f2.w);
+    const float rest = 1.0f - (s.alpha + beta);
+    const float u = __builtin_fminf(__builtin_fminf(s.alpha, beta), rest);
+    return !(u < 0.5f - s.thr);
 }
 
 // ray_tracing.cpp:169-206; the far root is replaced by the near one at :202 and that is kept
@@ -373,23 +385,23 @@ __global__ void __launch_bounds__(BLOCK) k_prep_triangles(const float* __restric
     o[1] = make_float4(ab.x, ab.y, ab.z, n.y);
     o[2] = make_float4(ac.x, ac.y, ac.z, n.z);
     o[3] = make_float4(nn, 0.0f, 0.0f, 0.0f);
-    // pre-test record (pretest_rejects): nothing here has to match the reference's rounding
+    // pre-test record (pretest_stage1): nothing here has to match the reference's rounding
     const float inv_nn = 1.0f / nn;
     const V3 w1 = scale(inv_nn, vcross(n, ab));
     const V3 w2 = scale(inv_nn, vcross(ac, n));
     const float n_max = fmaxf(fabsf(n.x), fmaxf(fabsf(n.y), fabsf(n.z)));
     const float e_max = fmaxf(fmaxf(fabsf(ab.x), fmaxf(fabsf(ab.y), fabsf(ab.z))), fmaxf(fabsf(ac.x), fmaxf(fabsf(ac.y), fabsf(ac.z))));
     const float a_max = fmaxf(fabsf(a.x), fmaxf(fabsf(a.y), fabsf(a.z)));
-    const float G = 1.0001f * (1.0f / 65536.0f) * (n_max * e_max * inv_nn);
+    const float G = 1.0001f * (1.0f / 32768.0f) * (n_max * e_max * inv_nn);
     const float H = 1.0001f * (G * a_max) + (1.0f / 4194304.0f);
     float4* q = outf + static_cast<size_t>(k) * 4;
-    q[0] = make_float4(n.x, n.y, n.z, -2.0f * G);
-    q[1] = make_float4(a.x, a.y, a.z, -2.0f * H);
+    q[0] = make_float4(n.x, n.y, n.z, 2.0f * G);
+    q[1] = make_float4(a.x, a.y, a.z, 2.0f * H + 0.5f);
     q[2] = make_float4(w1.x, w1.y, w1.z, 0.0f);
     q[3] = make_float4(w2.x, w2.y, w2.z, 0.0f);
 }
 
-// pre-test records for rays that all start at X (pretest_rejects_from)
+// pre-test records for rays that all start at X (pretest_from_stage1)
 __global__ void __launch_bounds__(BLOCK) k_prep_origin(const float4* __restrict__ tri, const float4* __restrict__ trif, uint32_t n_tri,
                                                        float x, float y, float z, float4* __restrict__ out) {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
@@ -402,10 +414,10 @@ __global__ void __launch_bounds__(BLOCK) k_prep_origin(const float4* __restrict_
     const float num = vdot(ao, n);                     // and its (a - o).n
     const float x_max = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
     float4* q = out + static_cast<size_t>(k) * 4;
-    q[0] = f0;
-    q[1] = make_float4(ao.x, ao.y, ao.z, 1.0001f * (f0.w * x_max) + f1.w);   // both terms are negative
-    q[2] = make_float4(f2.x, f2.y, f2.z, num);
-    q[3] = f3;
+    q[0] = make_float4(n.x, n.y, n.z, num);
+    q[1] = make_float4(f2.x, f2.y, f2.z, vdot(ao, xyz(f2)));
+    q[2] = make_float4(f3.x, f3.y, f3.z, vdot(ao, xyz(f3)));
+    q[3] = make_float4(f0.w, 1.0001f * (f0.w * x_max) + f1.w, 0.0f, 0.0f);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_prep_spheres(const float* __restrict__ sph8, uint32_t nb, float4* __restrict__ out) {
@@ -544,26 +556,51 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DevScene sc, State st, uint32
         __syncthreads();
         stage_tile<4>(lds, tri_stream, first, count);
         __syncthreads();
-#pragma unroll 2
-        for (uint32_t k = 0; k < count; ++k) {
-            const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
-            if (FILTER) {
-                bool survive = false;
+        auto full_test = [&](uint32_t k) {
+            // some lane may hit: the whole wave runs the full test on the full record
+            const float4* __restrict__ rec = sc.tri + static_cast<size_t>(first + k) * 4;
+            const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3];
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    survive |= MODE == 2 ? !pretest_rejects_from(d[r], t0, t1, t2, t3) : !pretest_rejects(o[r], d[r], o_max[r], t0, t1, t2, t3);
-                if (__any(survive)) {
-                    // some lane may hit: the whole wave runs the full test on the full record
-                    const float4* __restrict__ rec = sc.tri + static_cast<size_t>(first + k) * 4;
-                    const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3];
+            for (int r = 0; r < R; ++r) {
+                const float t = hit_triangle(o[r], d[r], e0, e1, e2, e3.x);
+                if (t < tri_t[r]) { tri_t[r] = t; tri_k[r] = first + k; }
+            }
+            n_full += R;
+        };
+        if (MODE == 2) {
+            for (uint32_t k = 0; k < count; ++k) {
+                const float4 f0 = lds[k * 4], f1 = lds[k * 4 + 1], f3 = lds[k * 4 + 3];
+                PreFrom pre[R];
+                bool keep = false;
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const float t = hit_triangle(o[r], d[r], e0, e1, e2, e3.x);
-                        if (t < tri_t[r]) { tri_t[r] = t; tri_k[r] = first + k; }
-                    }
-                    n_full += R;
+                for (int r = 0; r < R; ++r) keep |= pretest_from_stage1(d[r], f0, f1, f3, pre[r]);
+                if (__any(keep)) {
+                    const float4 f2 = lds[k * 4 + 2];
+                    keep = false;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) keep |= pretest_from_stage2(d[r], pre[r], f2);
+                    if (__any(keep)) full_test(k);
                 }
-            } else {
+            }
+        } else if (MODE == 1) {
+            for (uint32_t k = 0; k < count; ++k) {
+                const float4 f0 = lds[k * 4], f1 = lds[k * 4 + 1], f2 = lds[k * 4 + 2];
+                Pre pre[R];
+                bool keep = false;
+#pragma unroll
+                for (int r = 0; r < R; ++r) keep |= pretest_stage1(o[r], d[r], o_max[r], f0, f1, f2, pre[r]);
+                if (__any(keep)) {
+                    const float4 f3 = lds[k * 4 + 3];
+                    keep = false;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) keep |= pretest_stage2(pre[r], f3);
+                    if (__any(keep)) full_test(k);
+                }
+            }
+        } else {
+#pragma unroll 2
+            for (uint32_t k = 0; k < count; ++k) {
+                const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const float t = hit_triangle(o[r], d[r], t0, t1, t2, t3.x);
@@ -744,21 +781,31 @@ __global__ void __launch_bounds__(BLOCK, 6) k_shadow(DevScene sc, State st, uint
         __syncthreads();
         if (!done) {
             count_tests(0, count);
-#pragma unroll 2
-            for (uint32_t k = 0; k < count; ++k) {
-                const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
-                if (FILTER) {
-                    bool survive = false;
+            if (FILTER) {
+                for (uint32_t k = 0; k < count; ++k) {
+                    const float4 f0 = lds[k * 4], f1 = lds[k * 4 + 1], f2 = lds[k * 4 + 2];
+                    Pre pre[R];
+                    bool keep = false;
 #pragma unroll
-                    for (int r = 0; r < R; ++r) survive |= !pretest_rejects(o[r], d[r], o_max[r], t0, t1, t2, t3);
-                    if (__any(survive)) {
-                        const float4* __restrict__ rec = sc.tri + static_cast<size_t>(first + k) * 4;
-                        const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3];
+                    for (int r = 0; r < R; ++r) keep |= pretest_stage1(o[r], d[r], o_max[r], f0, f1, f2, pre[r]);
+                    if (__any(keep)) {
+                        const float4 f3 = lds[k * 4 + 3];
+                        keep = false;
 #pragma unroll
-                        for (int r = 0; r < R; ++r) blocked[r] |= hit_triangle(o[r], d[r], e0, e1, e2, e3.x) < limit[r];
-                        n_full += R;
+                        for (int r = 0; r < R; ++r) keep |= pretest_stage2(pre[r], f3);
+                        if (__any(keep)) {
+                            const float4* __restrict__ rec = sc.tri + static_cast<size_t>(first + k) * 4;
+                            const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3];
+#pragma unroll
+                            for (int r = 0; r < R; ++r) blocked[r] |= hit_triangle(o[r], d[r], e0, e1, e2, e3.x) < limit[r];
+                            n_full += R;
+                        }
                     }
-                } else {
+                }
+            } else {
+#pragma unroll 2
+                for (uint32_t k = 0; k < count; ++k) {
+                    const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
 #pragma unroll
                     for (int r = 0; r < R; ++r) blocked[r] |= hit_triangle(o[r], d[r], t0, t1, t2, t3.x) < limit[r];
                 }

@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# torch ships its own HIP/HSA runtime libraries.  They must be the first ones loaded in a process
+# that also loads librt_amd.so (linked against the system ROCm): loaded second, torch finds no GPU.
+try:
+    import torch  # noqa: F401
+except ImportError:  # the CPU-only checks that do not need torch still run
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
