@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -65,7 +66,8 @@ constexpr uint32_t SAMPLES_PER_TILE = RT_TILE * RT_TILE * RT_SAMPLES_PER_PIXEL; 
 struct DevScene {
     const float4* tri;   // 4 x float4 per triangle: (a, n.x) (a_to_b, n.y) (a_to_c, n.z) (n.n, 0, 0, 0)
     const float4* trif;  // pre-test records, 4 x float4 per triangle, see pretest_stage1
-    const float4* trio;  // pre-test records for rays from the camera eye, see pretest_from_stage1
+    const float4* strip_eye;    // strip records (2 x float4 per triangle) for rays from the camera eye, see strip_keeps
+    const float4* strip_light;  // [point light][triangle] strip records for shadow rays toward that light
     const float4* sph;   // (centre, radius)
     const float4* ell;   // 6 x float4: rows of the inverse transform, rows of the transform
     const float4* ell_light;  // [point light][ellipsoid]: inverse transform applied to the light position
@@ -81,6 +83,7 @@ struct DevScene {
     float bb[6];
     float ambient[3];
     float atten[3];
+    float origin_bound;   // every bounce / shadow ray starts within this max-norm distance of 0 (scene box + slack)
 };
 
 struct Frame {
@@ -251,24 +254,22 @@ DEV bool pretest_stage2(const Pre& s, float4 f3) {
     return !(u < 0.5f - s.thr);
 }
 
-// The same pre-test for rays that all start at one point X (the camera eye): (a - X).n,
-// c1 = w1.(a - X), c2 = w2.(a - X) and the |X|_inf part of the margin are per-triangle
-// constants prepared by k_prep_origin, and alpha1 = t1 (w1.d) - c1, beta1 = t1 (w2.d) - c2
-// (rounding bound 132 eps Q (...) as above).
-// Record: (n, (a - X).n) (w1, c1) (w2, c2) (Ga, Ga |X|_inf + Ha, 0, 0).
-struct PreFrom { float t1, alpha, thr; };
-DEV bool pretest_from_stage1(V3 d, float4 f0, float4 f1, float4 f3, PreFrom& s) {
-    const float dn = vdot(d, xyz(f0));
-    s.t1 = f0.w * __builtin_amdgcn_rcpf(dn);
-    s.alpha = fma_(s.t1, vdot(d, xyz(f1)), -f1.w);
-    s.thr = fma_(f3.x, __builtin_fabsf(s.t1), f3.y);
-    return !(__builtin_fabsf(s.alpha - 0.5f) > s.thr);
-}
-DEV bool pretest_from_stage2(V3 d, const PreFrom& s, float4 f2) {
-    const float beta = fma_(s.t1, vdot(d, xyz(f2)), -f2.w);
-    const float rest = 1.0f - (s.alpha + beta);
-    const float u = __builtin_fminf(__builtin_fminf(s.alpha, beta), rest);
-    return !(u < 0.5f - s.thr);
+// Strip pre-test for rays that pass through one common point X: camera rays (X = eye) and
+// shadow rays toward a point light (X = light position; the line is the same whichever end it
+// is walked from).  For such rays (a - X), num = (a - X).n and c1 = w1.(a - X) are per-triangle
+// constants, and with alpha = t (w1.d) - c1, t = num / (d.n):
+//     (alpha - 0.5) (d.n) = V.d,   V = num w1 - (c1 + 0.5) n        (a per-triangle vector)
+// so "alpha is outside [-2m, 1 + 2m]" becomes |V.d| > kappa |d.n| with kappa = 0.5 + 2m.  The
+// record holds n and V / kappa (k_prep_strip, computed in double): two dot products and one
+// compare per ray and triangle, no reciprocal.  kappa also covers the rounding of this form,
+// including the terms that do not scale with |d.n| (bounded through the full test's own
+// |d.n| >= tolerance); DESIGN.md "Strip pre-test".  A ray the strip keeps goes on to the
+// two-stage pre-test above and then to the full test.
+// Record: (n, Vs.x) (Vs.y, Vs.z, 0, 0) with Vs = V / kappa; Vs = 0 keeps every ray.
+DEV bool strip_keeps(V3 d, float4 s0, float4 s1) {
+    const float dn = vdot(d, xyz(s0));
+    const float x = vdot(d, V3{s0.w, s1.x, s1.y});
+    return !(__builtin_fabsf(x) > __builtin_fabsf(dn));
 }
 
 // ray_tracing.cpp:169-206; the far root is replaced by the near one at :202 and that is kept
@@ -401,23 +402,55 @@ __global__ void __launch_bounds__(BLOCK) k_prep_triangles(const float* __restric
     q[3] = make_float4(w2.x, w2.y, w2.z, 0.0f);
 }
 
-// pre-test records for rays that all start at X (pretest_from_stage1)
-__global__ void __launch_bounds__(BLOCK) k_prep_origin(const float4* __restrict__ tri, const float4* __restrict__ trif, uint32_t n_tri,
-                                                       float x, float y, float z, float4* __restrict__ out) {
+// Strip records (strip_keeps) for lines through X.  `reversed` = 1: X is a point light and the
+// full test walks the line from the other end (origin within origin_bound of 0, unit direction
+// rounded from (X - origin)); 0: X is the camera eye and the full test starts at X itself.
+// Everything is evaluated in double from the binary32 data; only a - X and (a - X).n are
+// taken in binary32, as the full test computes them.
+__global__ void __launch_bounds__(BLOCK) k_prep_strip(const float4* __restrict__ tri, uint32_t n_tri, float x, float y, float z,
+                                                      float origin_bound, int reversed, float4* __restrict__ out) {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= n_tri) return;
-    const float4 t0 = tri[static_cast<size_t>(k) * 4];
-    const float4* f = trif + static_cast<size_t>(k) * 4;
-    const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
-    const V3 n = xyz(f0);
-    const V3 ao = sub(xyz(t0), V3{x, y, z});          // the full test's a - o
-    const float num = vdot(ao, n);                     // and its (a - o).n
-    const float x_max = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
-    float4* q = out + static_cast<size_t>(k) * 4;
-    q[0] = make_float4(n.x, n.y, n.z, num);
-    q[1] = make_float4(f2.x, f2.y, f2.z, vdot(ao, xyz(f2)));
-    q[2] = make_float4(f3.x, f3.y, f3.z, vdot(ao, xyz(f3)));
-    q[3] = make_float4(f0.w, 1.0001f * (f0.w * x_max) + f1.w, 0.0f, 0.0f);
+    const float4 t0 = tri[static_cast<size_t>(k) * 4], t1 = tri[static_cast<size_t>(k) * 4 + 1], t2 = tri[static_cast<size_t>(k) * 4 + 2], t3 = tri[static_cast<size_t>(k) * 4 + 3];
+    const V3 a32 = xyz(t0), n32{t0.w, t1.w, t2.w};
+    const V3 ax32 = sub(a32, V3{x, y, z});
+    const double num = static_cast<double>(vdot(ax32, n32));
+    const double n[3] = {n32.x, n32.y, n32.z}, ab[3] = {t1.x, t1.y, t1.z}, ac[3] = {t2.x, t2.y, t2.z};
+    const double ax[3] = {ax32.x, ax32.y, ax32.z}, a[3] = {a32.x, a32.y, a32.z};
+    const double nn = static_cast<double>(t3.x);
+    const double w1[3] = {(n[1] * ab[2] - n[2] * ab[1]) / nn, (n[2] * ab[0] - n[0] * ab[2]) / nn, (n[0] * ab[1] - n[1] * ab[0]) / nn};
+    const double c1 = w1[0] * ax[0] + w1[1] * ax[1] + w1[2] * ax[2];
+    auto max3 = [](const double* v) { return fmax(fabs(v[0]), fmax(fabs(v[1]), fabs(v[2]))); };
+    auto len3 = [](const double* v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    const double eps = 5.9604644775390625e-8;   // 2^-24
+    const double n_max = max3(n), n_one = fabs(n[0]) + fabs(n[1]) + fabs(n[2]);
+    const double Q = n_max * fmax(max3(ab), max3(ac)) / nn;
+    const double edges = len3(ab) + len3(ac);
+    const double T_x = 2.0 * (len3(ax) + edges);                      // distance from X to any accepted hit, with slack
+    const double x_max = fmax(fabs(static_cast<double>(x)), fmax(fabs(static_cast<double>(y)), fabs(static_cast<double>(z))));
+    const double tol = 1.0e-4;
+    double tol_eff, S, bracket;
+    if (reversed) {
+        const double B = origin_bound;
+        const double T_p = 2.0 * (1.7320508075688772 * (max3(a) + B) + edges);   // distance from the full test's origin to the hit
+        tol_eff = tol - 8.0 * eps * n_one;
+        S = B + T_p + max3(a);
+        bracket = 48.0 * eps * Q * S + 12.0 * eps * Q * T_x + eps + 12.0 * eps * Q * T_p * (1.0 + n_one / tol_eff) + 6.0 * eps * Q * max3(ax);
+    } else {
+        tol_eff = 0.999 * tol;
+        S = x_max + T_x + max3(a);
+        bracket = 48.0 * eps * Q * S + 6.0 * eps * Q * T_x + eps;
+    }
+    bracket += eps * n_max * (198.0 * Q * max3(ax) + 11.0) / tol_eff;
+    const double kappa = (0.5 + 2.0 * bracket) * (1.0 + 4.0 * eps * n_one / tol_eff);
+    float vs[3] = {0.0f, 0.0f, 0.0f};
+    if (nn > 0.0 && tol_eff > 2.0e-5 && kappa < 1.0e30) {   // also false for NaN
+        for (int i = 0; i < 3; ++i) vs[i] = static_cast<float>((num * w1[i] - (c1 + 0.5) * n[i]) / kappa);
+        if (!(fabsf(vs[0]) < 1.0e30f && fabsf(vs[1]) < 1.0e30f && fabsf(vs[2]) < 1.0e30f)) vs[0] = vs[1] = vs[2] = 0.0f;
+    }
+    float4* q = out + static_cast<size_t>(k) * 2;
+    q[0] = make_float4(n32.x, n32.y, n32.z, vs[0]);
+    q[1] = make_float4(vs[1], vs[2], 0.0f, 0.0f);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_prep_spheres(const float* __restrict__ sph8, uint32_t nb, float4* __restrict__ out) {
@@ -507,8 +540,17 @@ __global__ void __launch_bounds__(BLOCK) k_primary(Frame f, DevScene sc, State s
 }
 
 // ------------------------------------------------------------------------------------------
-// k_closest: closest hit of every live ray against every primitive, then the per-hit set-up
+// closest-hit scans: one kernel per primitive kind, then k_hit
 // ------------------------------------------------------------------------------------------
+// Each kind has its own kernel so that the triangle scan, where the time goes, is compiled with
+// only the registers its own loop needs.  A scan leaves (distance, scan index) of its kind in the
+// ray's state; k_hit combines the three.  The result slots reuse the arrays that k_hit itself
+// fills afterwards (hit point and normal), which nothing reads in between.
+DEV float* closest_t_slot(const State& st, int kind) { return kind == 0 ? st.px : (kind == 1 ? st.pz : st.ny); }
+DEV uint32_t* closest_k_slot(const State& st, int kind) {
+    return reinterpret_cast<uint32_t*>(kind == 0 ? st.py : (kind == 1 ? st.nx : st.nz));
+}
+
 // LDS staging: a tile of `count` records of WORDS float4 each is copied by the whole
 // workgroup; `lds` must hold TILE_PRIMS * WORDS float4.
 template <int WORDS>
@@ -518,20 +560,10 @@ DEV void stage_tile(float4* lds, const float4* __restrict__ src, uint32_t first,
     for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) lds[i] = g[i];
 }
 
-// MODE 0: every triangle through the full test; 1: pre-test first; 2: pre-test for rays from the eye (bounce 0)
-template <int R, int MODE>
-__global__ void __launch_bounds__(BLOCK) k_closest(DevScene sc, State st, uint32_t bounce) {
-    constexpr bool FILTER = MODE != 0;
-    __shared__ float4 lds[TILE_PRIMS * 6];
-    __shared__ uint32_t lds_scan[8];
-    const uint32_t n_rays = st.counts[bounce];
-    const uint32_t base = blockIdx.x * (BLOCK * R);
-    if (base >= n_rays) return;
-    const uint32_t* __restrict__ list_in = st.list[bounce & 1u];
-
-    uint32_t slot[R];
-    bool valid[R];
-    V3 o[R], d[R];
+// rays base + r*BLOCK + thread of the live list; lanes past the end repeat the first ray and are not stored
+template <int R>
+DEV void load_rays(const State& st, const uint32_t* __restrict__ list_in, uint32_t base, uint32_t n_rays,
+                   uint32_t (&slot)[R], bool (&valid)[R], V3 (&o)[R], V3 (&d)[R]) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t i = base + r * BLOCK + threadIdx.x;
@@ -540,21 +572,35 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DevScene sc, State st, uint32
         o[r] = {st.ox[slot[r]], st.oy[slot[r]], st.oz[slot[r]]};
         d[r] = {st.dx[slot[r]], st.dy[slot[r]], st.dz[slot[r]]};
     }
+}
 
-    // ---- triangles ----
-    float tri_t[R]; uint32_t tri_k[R];
+// MODE 0: every triangle through the full test; 1: two-stage pre-test first;
+// 2: strip pre-test (rays from the eye, bounce 0), then the two-stage pre-test, then the full test
+template <int R, int MODE>
+__global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, uint32_t bounce) {
+    __shared__ float4 lds[TILE_PRIMS * (MODE == 2 ? 2 : 4)];
+    const uint32_t n_rays = st.counts[bounce];
+    const uint32_t base = blockIdx.x * (BLOCK * R);
+    if (base >= n_rays) return;
+
+    uint32_t slot[R];
+    bool valid[R];
+    V3 o[R], d[R];
+    load_rays<R>(st, st.list[bounce & 1u], base, n_rays, slot, valid, o, d);
+
+    float best_t[R]; uint32_t best_k[R];
     float o_max[R];   // pre-test only: |o|_inf
-    unsigned long long n_full = 0;
+    uint32_t n_full = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        tri_t[r] = FLT_MAX; tri_k[r] = 0xFFFFFFFFu;
+        best_t[r] = FLT_MAX; best_k[r] = 0xFFFFFFFFu;
         o_max[r] = fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z)));
     }
-    const float4* __restrict__ tri_stream = MODE == 2 ? sc.trio : (MODE == 1 ? sc.trif : sc.tri);
+    const float4* __restrict__ tri_stream = MODE == 2 ? sc.strip_eye : (MODE == 1 ? sc.trif : sc.tri);
     for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
         __syncthreads();
-        stage_tile<4>(lds, tri_stream, first, count);
+        stage_tile<(MODE == 2 ? 2 : 4)>(lds, tri_stream, first, count);
         __syncthreads();
         auto full_test = [&](uint32_t k) {
             // some lane may hit: the whole wave runs the full test on the full record
@@ -563,22 +609,23 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DevScene sc, State st, uint32
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float t = hit_triangle(o[r], d[r], e0, e1, e2, e3.x);
-                if (t < tri_t[r]) { tri_t[r] = t; tri_k[r] = first + k; }
+                if (t < best_t[r]) { best_t[r] = t; best_k[r] = first + k; }
             }
             n_full += R;
         };
         if (MODE == 2) {
             for (uint32_t k = 0; k < count; ++k) {
-                const float4 f0 = lds[k * 4], f1 = lds[k * 4 + 1], f3 = lds[k * 4 + 3];
-                PreFrom pre[R];
+                const float4 s0 = lds[k * 2], s1 = lds[k * 2 + 1];
                 bool keep = false;
 #pragma unroll
-                for (int r = 0; r < R; ++r) keep |= pretest_from_stage1(d[r], f0, f1, f3, pre[r]);
+                for (int r = 0; r < R; ++r) keep |= strip_keeps(d[r], s0, s1);
                 if (__any(keep)) {
-                    const float4 f2 = lds[k * 4 + 2];
+                    const float4* __restrict__ f = sc.trif + static_cast<size_t>(first + k) * 4;
+                    const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
+                    Pre pre[R];
                     keep = false;
 #pragma unroll
-                    for (int r = 0; r < R; ++r) keep |= pretest_from_stage2(d[r], pre[r], f2);
+                    for (int r = 0; r < R; ++r) keep |= pretest_stage1(o[r], d[r], o_max[r], f0, f1, f2, pre[r]) && pretest_stage2(pre[r], f3);
                     if (__any(keep)) full_test(k);
                 }
             }
@@ -604,15 +651,31 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DevScene sc, State st, uint32
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const float t = hit_triangle(o[r], d[r], t0, t1, t2, t3.x);
-                    if (t < tri_t[r]) { tri_t[r] = t; tri_k[r] = first + k; }
+                    if (t < best_t[r]) { best_t[r] = t; best_k[r] = first + k; }
                 }
             }
         }
     }
-    // ---- spheres ----
-    float sph_t[R]; uint32_t sph_k[R];
+    float* out_t = closest_t_slot(st, 0);
+    uint32_t* out_k = closest_k_slot(st, 0);
 #pragma unroll
-    for (int r = 0; r < R; ++r) { sph_t[r] = FLT_MAX; sph_k[r] = 0xFFFFFFFFu; }
+    for (int r = 0; r < R; ++r) if (valid[r]) { out_t[slot[r]] = best_t[r]; out_k[slot[r]] = best_k[r]; }
+    if (MODE != 0) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
+}
+
+template <int R>
+__global__ void __launch_bounds__(BLOCK) k_closest_sph(DevScene sc, State st, uint32_t bounce) {
+    __shared__ float4 lds[TILE_PRIMS];
+    const uint32_t n_rays = st.counts[bounce];
+    const uint32_t base = blockIdx.x * (BLOCK * R);
+    if (base >= n_rays) return;
+    uint32_t slot[R];
+    bool valid[R];
+    V3 o[R], d[R];
+    load_rays<R>(st, st.list[bounce & 1u], base, n_rays, slot, valid, o, d);
+    float best_t[R]; uint32_t best_k[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { best_t[r] = FLT_MAX; best_k[r] = 0xFFFFFFFFu; }
     for (uint32_t first = 0; first < sc.n_sph; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_sph - first);
         __syncthreads();
@@ -624,14 +687,29 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DevScene sc, State st, uint32
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float t = hit_sphere(o[r], d[r], s);
-                if (t < sph_t[r]) { sph_t[r] = t; sph_k[r] = first + k; }
+                if (t < best_t[r]) { best_t[r] = t; best_k[r] = first + k; }
             }
         }
     }
-    // ---- ellipsoids ----
-    float ell_t[R]; uint32_t ell_k[R];
+    float* out_t = closest_t_slot(st, 1);
+    uint32_t* out_k = closest_k_slot(st, 1);
 #pragma unroll
-    for (int r = 0; r < R; ++r) { ell_t[r] = FLT_MAX; ell_k[r] = 0xFFFFFFFFu; }
+    for (int r = 0; r < R; ++r) if (valid[r]) { out_t[slot[r]] = best_t[r]; out_k[slot[r]] = best_k[r]; }
+}
+
+template <int R>
+__global__ void __launch_bounds__(BLOCK) k_closest_ell(DevScene sc, State st, uint32_t bounce) {
+    __shared__ float4 lds[TILE_PRIMS * 6];
+    const uint32_t n_rays = st.counts[bounce];
+    const uint32_t base = blockIdx.x * (BLOCK * R);
+    if (base >= n_rays) return;
+    uint32_t slot[R];
+    bool valid[R];
+    V3 o[R], d[R];
+    load_rays<R>(st, st.list[bounce & 1u], base, n_rays, slot, valid, o, d);
+    float best_t[R]; uint32_t best_k[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { best_t[r] = FLT_MAX; best_k[r] = 0xFFFFFFFFu; }
     for (uint32_t first = 0; first < sc.n_ell; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_ell - first);
         __syncthreads();
@@ -643,151 +721,216 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DevScene sc, State st, uint32
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float t = hit_ellipsoid(o[r], d[r], i0, i1, i2, m0, m1, m2);
-                if (t < ell_t[r]) { ell_t[r] = t; ell_k[r] = first + k; }
+                if (t < best_t[r]) { best_t[r] = t; best_k[r] = first + k; }
             }
         }
     }
-
-    // ---- per-ray epilogue: kind choice, hit point, normal, ambient + emission ----
-    unsigned long long n_valid = 0, n_hit = 0;
+    float* out_t = closest_t_slot(st, 2);
+    uint32_t* out_k = closest_k_slot(st, 2);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t s = slot[r];
-        const bool any = (tri_k[r] != 0xFFFFFFFFu) | (sph_k[r] != 0xFFFFFFFFu) | (ell_k[r] != 0xFFFFFFFFu);
-        // ray_tracing.cpp:616, :637, :655
-        int kind = -1;
-        if (any) {
-            if (tri_t[r] - sph_t[r] <= TOL && tri_t[r] - ell_t[r] <= TOL) kind = 0;
-            else if (sph_t[r] - tri_t[r] <= TOL && sph_t[r] - ell_t[r] <= TOL) kind = 1;
-            else if (ell_t[r] - tri_t[r] <= TOL && ell_t[r] - sph_t[r] <= TOL) kind = 2;
-        }
-        const bool hit = valid[r] && kind >= 0;
-        if (hit) {
-            V3 p, n;
-            uint32_t index;
-            const float* mat;
-            uint32_t mat_count;
-            if (kind == 0) {
-                const uint32_t k = tri_k[r];
-                index = 8u * (k % sc.tri_nb) + k / sc.tri_nb;
-                p = add(o[r], scale(tri_t[r], d[r]));
-                const float4 t0 = sc.tri[static_cast<size_t>(k) * 4], t1 = sc.tri[static_cast<size_t>(k) * 4 + 1], t2 = sc.tri[static_cast<size_t>(k) * 4 + 2];
-                const V3 a = xyz(t0);
-                const V3 vb = add(xyz(t1), a), vc = add(xyz(t2), a);      // ray_tracing.cpp:631-632
-                n = normalise(scross(sub(vb, a), sub(vc, a)));            // maths.cpp:304-306
-                mat = sc.tri_mat; mat_count = sc.n_tri_mat;
-            } else if (kind == 1) {
-                const uint32_t k = sph_k[r];
-                index = 8u * (k % sc.sph_nb) + k / sc.sph_nb;
-                p = add(o[r], scale(sph_t[r], d[r]));
-                n = normalise(sub(p, xyz(sc.sph[k])));                    // maths.cpp:308-310
-                mat = sc.sph_mat; mat_count = sc.n_sph_mat;
-            } else {
-                const uint32_t k = ell_k[r];
-                index = 8u * (k % sc.ell_nb) + k / sc.ell_nb;
-                p = add(o[r], scale(ell_t[r], d[r]));
-                const float4 i0 = sc.ell[static_cast<size_t>(k) * 6], i1 = sc.ell[static_cast<size_t>(k) * 6 + 1], i2 = sc.ell[static_cast<size_t>(k) * 6 + 2];
-                const V3 pe = smat_point(i0, i1, i2, p);                  // maths.cpp:320-326
-                const V3 ne = normalise(pe);
-                n = normalise(smat_transpose_dir(i0, i1, i2, ne));
-                mat = sc.ell_mat; mat_count = sc.n_ell_mat;
-            }
-            // A hit on a zero-padding lane has no material; the reference reads past its vector there.
-            float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
-            if (index < mat_count) { e0 = mat[index * 10 + 6]; e1 = mat[index * 10 + 7]; e2 = mat[index * 10 + 8]; }
-            st.cr[s] += st.wr[s] * (sc.ambient[0] + e0);                   // ray_tracing.cpp:682
-            st.cg[s] += st.wg[s] * (sc.ambient[1] + e1);
-            st.cb[s] += st.wb[s] * (sc.ambient[2] + e2);
-            st.px[s] = p.x; st.py[s] = p.y; st.pz[s] = p.z;
-            st.nx[s] = n.x; st.ny[s] = n.y; st.nz[s] = n.z;
-            const uint32_t id = RT_ID_MAKE(static_cast<uint32_t>(kind), index);
-            st.hit_id[s] = id;
-            st.blocked[s] = 0u;
-            if (bounce == 0 && st.primary_id) st.primary_id[s] = id;
-        }
-        const uint32_t pos = block_append(hit, &st.counts[bounce + 1], lds_scan);
-        if (hit) st.list[(bounce + 1) & 1u][pos] = s;
-        __syncthreads();
-        n_valid += valid[r] ? 1ull : 0ull;
-        n_hit += hit ? 1ull : 0ull;
+    for (int r = 0; r < R; ++r) if (valid[r]) { out_t[slot[r]] = best_t[r]; out_k[slot[r]] = best_k[r]; }
+}
+
+// k_hit: one ray per thread.  Kind choice (ray_tracing.cpp:610-680), hit point, normal,
+// ambient + emission (:682), and the order-preserving list of rays that go on.
+__global__ void __launch_bounds__(BLOCK) k_hit(DevScene sc, State st, uint32_t bounce) {
+    __shared__ uint32_t lds_scan[8];
+    const uint32_t n_rays = st.counts[bounce];
+    const uint32_t base = blockIdx.x * BLOCK;
+    if (base >= n_rays) return;
+    const uint32_t i = base + threadIdx.x;
+    const bool valid = i < n_rays;
+    const uint32_t s = st.list[bounce & 1u][valid ? i : base];
+
+    float t_kind[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+    uint32_t k_kind[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (sc.n_tri) { t_kind[0] = closest_t_slot(st, 0)[s]; k_kind[0] = closest_k_slot(st, 0)[s]; }
+    if (sc.n_sph) { t_kind[1] = closest_t_slot(st, 1)[s]; k_kind[1] = closest_k_slot(st, 1)[s]; }
+    if (sc.n_ell) { t_kind[2] = closest_t_slot(st, 2)[s]; k_kind[2] = closest_k_slot(st, 2)[s]; }
+    const float tri_t = t_kind[0], sph_t = t_kind[1], ell_t = t_kind[2];
+    const bool any = (k_kind[0] != 0xFFFFFFFFu) | (k_kind[1] != 0xFFFFFFFFu) | (k_kind[2] != 0xFFFFFFFFu);
+    // ray_tracing.cpp:616, :637, :655
+    int kind = -1;
+    if (any) {
+        if (tri_t - sph_t <= TOL && tri_t - ell_t <= TOL) kind = 0;
+        else if (sph_t - tri_t <= TOL && sph_t - ell_t <= TOL) kind = 1;
+        else if (ell_t - tri_t <= TOL && ell_t - sph_t <= TOL) kind = 2;
     }
-    block_add_stat(&st.stats[ST_CLOSEST_RAYS], n_valid);
-    block_add_stat(&st.stats[ST_HITS], n_hit);
-    if (FILTER) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
+    const bool hit = valid && kind >= 0;
+    if (hit) {
+        const V3 o{st.ox[s], st.oy[s], st.oz[s]};
+        const V3 d{st.dx[s], st.dy[s], st.dz[s]};
+        V3 p, n;
+        uint32_t index;
+        const float* mat;
+        uint32_t mat_count;
+        if (kind == 0) {
+            const uint32_t k = k_kind[0];
+            index = 8u * (k % sc.tri_nb) + k / sc.tri_nb;
+            p = add(o, scale(tri_t, d));
+            const float4 t0 = sc.tri[static_cast<size_t>(k) * 4], t1 = sc.tri[static_cast<size_t>(k) * 4 + 1], t2 = sc.tri[static_cast<size_t>(k) * 4 + 2];
+            const V3 a = xyz(t0);
+            const V3 vb = add(xyz(t1), a), vc = add(xyz(t2), a);      // ray_tracing.cpp:631-632
+            n = normalise(scross(sub(vb, a), sub(vc, a)));            // maths.cpp:304-306
+            mat = sc.tri_mat; mat_count = sc.n_tri_mat;
+        } else if (kind == 1) {
+            const uint32_t k = k_kind[1];
+            index = 8u * (k % sc.sph_nb) + k / sc.sph_nb;
+            p = add(o, scale(sph_t, d));
+            n = normalise(sub(p, xyz(sc.sph[k])));                    // maths.cpp:308-310
+            mat = sc.sph_mat; mat_count = sc.n_sph_mat;
+        } else {
+            const uint32_t k = k_kind[2];
+            index = 8u * (k % sc.ell_nb) + k / sc.ell_nb;
+            p = add(o, scale(ell_t, d));
+            const float4 i0 = sc.ell[static_cast<size_t>(k) * 6], i1 = sc.ell[static_cast<size_t>(k) * 6 + 1], i2 = sc.ell[static_cast<size_t>(k) * 6 + 2];
+            const V3 pe = smat_point(i0, i1, i2, p);                  // maths.cpp:320-326
+            const V3 ne = normalise(pe);
+            n = normalise(smat_transpose_dir(i0, i1, i2, ne));
+            mat = sc.ell_mat; mat_count = sc.n_ell_mat;
+        }
+        // A hit on a zero-padding lane has no material; the reference reads past its vector there.
+        float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
+        if (index < mat_count) { e0 = mat[index * 10 + 6]; e1 = mat[index * 10 + 7]; e2 = mat[index * 10 + 8]; }
+        st.cr[s] += st.wr[s] * (sc.ambient[0] + e0);                   // ray_tracing.cpp:682
+        st.cg[s] += st.wg[s] * (sc.ambient[1] + e1);
+        st.cb[s] += st.wb[s] * (sc.ambient[2] + e2);
+        st.px[s] = p.x; st.py[s] = p.y; st.pz[s] = p.z;
+        st.nx[s] = n.x; st.ny[s] = n.y; st.nz[s] = n.z;
+        const uint32_t id = RT_ID_MAKE(static_cast<uint32_t>(kind), index);
+        st.hit_id[s] = id;
+        st.blocked[s] = 0u;
+        if (bounce == 0 && st.primary_id) st.primary_id[s] = id;
+    }
+    const uint32_t pos = block_append(hit, &st.counts[bounce + 1], lds_scan);
+    if (hit) st.list[(bounce + 1) & 1u][pos] = s;
+    block_add_stat(&st.stats[ST_CLOSEST_RAYS], valid ? 1ull : 0ull);
+    block_add_stat(&st.stats[ST_HITS], hit ? 1ull : 0ull);
 }
 
 // ------------------------------------------------------------------------------------------
-// k_shadow: any-hit of every hit point toward light (first_light + blockIdx.y)
+// shadow scans: any-hit of every hit point toward light (first_light + blockIdx.y), per kind
 // ------------------------------------------------------------------------------------------
-template <int R, bool FILTER>
-__global__ void __launch_bounds__(BLOCK, 6) k_shadow(DevScene sc, State st, uint32_t bounce, uint32_t first_light) {
-    __shared__ float4 lds[TILE_PRIMS * 4];
-    const uint32_t n_rays = st.counts[bounce + 1];
-    const uint32_t base = blockIdx.x * (BLOCK * R);
-    if (base >= n_rays) return;
-    const uint32_t* __restrict__ list_in = st.list[(bounce + 1) & 1u];
-    const uint32_t light = first_light + blockIdx.y;
-    const float* __restrict__ L = sc.lights + light * 8;
-    const bool point = L[0] != 0.0f;
-    const V3 lv{L[1], L[2], L[3]};
-
+// Shadow rays of one launch: origin above the surface (ray_tracing.cpp:685-686), direction and
+// limit per light kind (:350-354, :410-412).  A ray some earlier kind already blocked starts blocked.
+template <int R>
+struct ShadowRays {
     uint32_t slot[R];
     bool valid[R], blocked[R];
     V3 o[R], d[R];
     float limit[R];
-    // tests actually spent on undecided rays, per kind; wave-uniform (kept in scalar registers)
-    unsigned long long wave_tests[3] = {0, 0, 0};
-    auto count_tests = [&](int kind, uint32_t count) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) wave_tests[kind] += static_cast<unsigned long long>(count) * __popcll(__ballot(valid[r] && !blocked[r]));
-    };
+};
+template <int R>
+DEV void load_shadow_rays(const State& st, const uint32_t* __restrict__ list_in, uint32_t base, uint32_t n_rays,
+                          bool point, V3 lv, uint32_t light_bit, ShadowRays<R>& s) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t i = base + r * BLOCK + threadIdx.x;
-        valid[r] = i < n_rays;
-        slot[r] = list_in[valid[r] ? i : base];
-        const V3 p{st.px[slot[r]], st.py[slot[r]], st.pz[slot[r]]};
-        const V3 n{st.nx[slot[r]], st.ny[slot[r]], st.nz[slot[r]]};
-        o[r] = add(p, scale(2.0f * TOL, n));                               // ray_tracing.cpp:685-686
-        if (point) {                                                       // ray_tracing.cpp:350-354
-            const V3 to_light = sub(lv, o[r]);
-            limit[r] = sqrt_(sdot(to_light, to_light));
-            const float inv = 1.0f / limit[r];
-            d[r] = scale(inv, to_light);
-        } else {                                                           // ray_tracing.cpp:410-412
-            d[r] = scale(-1.0f, lv);
-            limit[r] = FLT_MAX;
+        s.valid[r] = i < n_rays;
+        s.slot[r] = list_in[s.valid[r] ? i : base];
+        const V3 p{st.px[s.slot[r]], st.py[s.slot[r]], st.pz[s.slot[r]]};
+        const V3 n{st.nx[s.slot[r]], st.ny[s.slot[r]], st.nz[s.slot[r]]};
+        s.o[r] = add(p, scale(2.0f * TOL, n));
+        if (point) {
+            const V3 to_light = sub(lv, s.o[r]);
+            s.limit[r] = sqrt_(sdot(to_light, to_light));
+            const float inv = 1.0f / s.limit[r];
+            s.d[r] = scale(inv, to_light);
+        } else {
+            s.d[r] = scale(-1.0f, lv);
+            s.limit[r] = FLT_MAX;
         }
-        blocked[r] = false;
+        s.blocked[r] = (st.blocked[s.slot[r]] & light_bit) != 0u;
+    }
+}
+template <int R>
+DEV bool shadow_wave_done(const ShadowRays<R>& s) {
+    bool all = true;
+#pragma unroll
+    for (int r = 0; r < R; ++r) all = all && (s.blocked[r] || !s.valid[r]);
+    return __all(all) != 0;
+}
+// tests spent on still-undecided rays of this wave, for `count` primitives (wave-uniform)
+template <int R>
+DEV unsigned long long shadow_live_tests(const ShadowRays<R>& s, uint32_t count) {
+    unsigned long long n = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) n += static_cast<unsigned long long>(count) * __popcll(__ballot(s.valid[r] && !s.blocked[r]));
+    return n;
+}
+template <int R>
+DEV void store_shadow_result(const State& st, const ShadowRays<R>& s, uint32_t light_bit, unsigned long long* stat, unsigned long long wave_tests) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (s.valid[r] && s.blocked[r]) atomicOr(&st.blocked[s.slot[r]], light_bit);
+    if ((threadIdx.x & 63u) == 0 && wave_tests) atomicAdd(stat, wave_tests);
+}
+
+// MODE 0: full test only; 1: two-stage pre-test; 2: strip pre-test first (point lights only:
+// lights first_light.. are point lights and their strip records start at sc.strip_light)
+template <int R, int MODE>
+__global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
+    constexpr bool FILTER = MODE != 0;
+    __shared__ float4 lds[TILE_PRIMS * (MODE == 2 ? 2 : 4)];
+    const uint32_t n_rays = st.counts[bounce + 1];
+    const uint32_t base = blockIdx.x * (BLOCK * R);
+    if (base >= n_rays) return;
+    const uint32_t light = first_light + blockIdx.y;
+    const float* __restrict__ L = sc.lights + light * 8;
+    const uint32_t light_bit = 1u << (light - group_first);
+    const V3 lv{L[1], L[2], L[3]};
+    ShadowRays<R> s;
+    load_shadow_rays<R>(st, st.list[(bounce + 1) & 1u], base, n_rays, L[0] != 0.0f, lv, light_bit, s);
+    float o_max[R];
+    V3 line[R];   // MODE 2: un-normalised direction of the line through the light, NaN where the strip test must not reject
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        o_max[r] = fmaxf(fabsf(s.o[r].x), fmaxf(fabsf(s.o[r].y), fabsf(s.o[r].z)));
+        line[r] = sub(lv, s.o[r]);
+        if (!(o_max[r] <= sc.origin_bound)) line[r].x = __builtin_nanf("");
     }
 
-    auto wave_done = [&]() {
-        bool all = true;
-#pragma unroll
-        for (int r = 0; r < R; ++r) all = all && (blocked[r] || !valid[r]);
-        return __all(all) != 0;
-    };
-    bool done = wave_done();
-
-    float o_max[R];
-    unsigned long long n_full = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) o_max[r] = fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z)));
-    const float4* __restrict__ tri_stream = FILTER ? sc.trif : sc.tri;
+    unsigned long long wave_tests = 0;
+    uint32_t n_full = 0;
+    bool done = shadow_wave_done<R>(s);
+    const float4* __restrict__ tri_stream = MODE == 2 ? sc.strip_light + static_cast<size_t>(light - sc.has_directional) * sc.n_tri * 2
+                                                      : (MODE == 1 ? sc.trif : sc.tri);
     for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
         if (__syncthreads_and(done)) break;
-        stage_tile<4>(lds, tri_stream, first, count);
+        stage_tile<(MODE == 2 ? 2 : 4)>(lds, tri_stream, first, count);
         __syncthreads();
         if (!done) {
-            count_tests(0, count);
-            if (FILTER) {
+            wave_tests += shadow_live_tests<R>(s, count);
+            if (MODE == 2) {
+                for (uint32_t k = 0; k < count; ++k) {
+                    const float4 s0 = lds[k * 2], s1 = lds[k * 2 + 1];
+                    bool keep = false;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) keep |= strip_keeps(line[r], s0, s1);
+                    if (__any(keep)) {
+                        const float4* __restrict__ f = sc.trif + static_cast<size_t>(first + k) * 4;
+                        const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
+                        Pre pre[R];
+                        keep = false;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) keep |= pretest_stage1(s.o[r], s.d[r], o_max[r], f0, f1, f2, pre[r]) && pretest_stage2(pre[r], f3);
+                        if (__any(keep)) {
+                            const float4* __restrict__ rec = sc.tri + static_cast<size_t>(first + k) * 4;
+                            const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3];
+#pragma unroll
+                            for (int r = 0; r < R; ++r) s.blocked[r] |= hit_triangle(s.o[r], s.d[r], e0, e1, e2, e3.x) < s.limit[r];
+                            n_full += R;
+                        }
+                    }
+                }
+            } else if (MODE == 1) {
                 for (uint32_t k = 0; k < count; ++k) {
                     const float4 f0 = lds[k * 4], f1 = lds[k * 4 + 1], f2 = lds[k * 4 + 2];
                     Pre pre[R];
                     bool keep = false;
 #pragma unroll
-                    for (int r = 0; r < R; ++r) keep |= pretest_stage1(o[r], d[r], o_max[r], f0, f1, f2, pre[r]);
+                    for (int r = 0; r < R; ++r) keep |= pretest_stage1(s.o[r], s.d[r], o_max[r], f0, f1, f2, pre[r]);
                     if (__any(keep)) {
                         const float4 f3 = lds[k * 4 + 3];
                         keep = false;
@@ -797,7 +940,7 @@ __global__ void __launch_bounds__(BLOCK, 6) k_shadow(DevScene sc, State st, uint
                             const float4* __restrict__ rec = sc.tri + static_cast<size_t>(first + k) * 4;
                             const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3];
 #pragma unroll
-                            for (int r = 0; r < R; ++r) blocked[r] |= hit_triangle(o[r], d[r], e0, e1, e2, e3.x) < limit[r];
+                            for (int r = 0; r < R; ++r) s.blocked[r] |= hit_triangle(s.o[r], s.d[r], e0, e1, e2, e3.x) < s.limit[r];
                             n_full += R;
                         }
                     }
@@ -807,28 +950,61 @@ __global__ void __launch_bounds__(BLOCK, 6) k_shadow(DevScene sc, State st, uint
                 for (uint32_t k = 0; k < count; ++k) {
                     const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) blocked[r] |= hit_triangle(o[r], d[r], t0, t1, t2, t3.x) < limit[r];
+                    for (int r = 0; r < R; ++r) s.blocked[r] |= hit_triangle(s.o[r], s.d[r], t0, t1, t2, t3.x) < s.limit[r];
                 }
             }
-            done = wave_done();
+            done = shadow_wave_done<R>(s);
         }
     }
+    store_shadow_result<R>(st, s, light_bit, &st.stats[ST_SHADOW_TESTS_TRI], wave_tests);
+    if (FILTER) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
+}
+
+template <int R>
+__global__ void __launch_bounds__(BLOCK) k_shadow_sph(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
+    __shared__ float4 lds[TILE_PRIMS];
+    const uint32_t n_rays = st.counts[bounce + 1];
+    const uint32_t base = blockIdx.x * (BLOCK * R);
+    if (base >= n_rays) return;
+    const float* __restrict__ L = sc.lights + (first_light + blockIdx.y) * 8;
+    const uint32_t light_bit = 1u << (first_light + blockIdx.y - group_first);
+    ShadowRays<R> s;
+    load_shadow_rays<R>(st, st.list[(bounce + 1) & 1u], base, n_rays, L[0] != 0.0f, V3{L[1], L[2], L[3]}, light_bit, s);
+    unsigned long long wave_tests = 0;
+    bool done = shadow_wave_done<R>(s);
     for (uint32_t first = 0; first < sc.n_sph; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_sph - first);
         if (__syncthreads_and(done)) break;
         stage_tile<1>(lds, sc.sph, first, count);
         __syncthreads();
         if (!done) {
-            count_tests(1, count);
+            wave_tests += shadow_live_tests<R>(s, count);
 #pragma unroll 2
             for (uint32_t k = 0; k < count; ++k) {
-                const float4 s = lds[k];
+                const float4 sp = lds[k];
 #pragma unroll
-                for (int r = 0; r < R; ++r) blocked[r] |= hit_sphere(o[r], d[r], s) < limit[r];
+                for (int r = 0; r < R; ++r) s.blocked[r] |= hit_sphere(s.o[r], s.d[r], sp) < s.limit[r];
             }
-            done = wave_done();
+            done = shadow_wave_done<R>(s);
         }
     }
+    store_shadow_result<R>(st, s, light_bit, &st.stats[ST_SHADOW_TESTS_SPH], wave_tests);
+}
+
+template <int R>
+__global__ void __launch_bounds__(BLOCK) k_shadow_ell(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
+    __shared__ float4 lds[TILE_PRIMS * 4];
+    const uint32_t n_rays = st.counts[bounce + 1];
+    const uint32_t base = blockIdx.x * (BLOCK * R);
+    if (base >= n_rays) return;
+    const uint32_t light = first_light + blockIdx.y;
+    const float* __restrict__ L = sc.lights + light * 8;
+    const bool point = L[0] != 0.0f;
+    const uint32_t light_bit = 1u << (light - group_first);
+    ShadowRays<R> s;
+    load_shadow_rays<R>(st, st.list[(bounce + 1) & 1u], base, n_rays, point, V3{L[1], L[2], L[3]}, light_bit, s);
+    unsigned long long wave_tests = 0;
+    bool done = shadow_wave_done<R>(s);
     const uint32_t point_index = light - sc.has_directional;   // index among the point lights
     for (uint32_t first = 0; first < sc.n_ell; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_ell - first);
@@ -841,32 +1017,16 @@ __global__ void __launch_bounds__(BLOCK, 6) k_shadow(DevScene sc, State st, uint
         }
         __syncthreads();
         if (!done) {
-            count_tests(2, count);
+            wave_tests += shadow_live_tests<R>(s, count);
             for (uint32_t k = 0; k < count; ++k) {
                 const float4 i0 = lds[k * 4], i1 = lds[k * 4 + 1], i2 = lds[k * 4 + 2], l2 = lds[k * 4 + 3];
 #pragma unroll
-                for (int r = 0; r < R; ++r) blocked[r] |= ellipsoid_blocks(o[r], d[r], i0, i1, i2, point, xyz(l2));
+                for (int r = 0; r < R; ++r) s.blocked[r] |= ellipsoid_blocks(s.o[r], s.d[r], i0, i1, i2, point, xyz(l2));
             }
-            done = wave_done();
+            done = shadow_wave_done<R>(s);
         }
     }
-
-    unsigned long long n_valid = 0, n_blocked = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (valid[r]) {
-            n_valid++;
-            if (blocked[r]) { n_blocked++; atomicOr(&st.blocked[slot[r]], 1u << blockIdx.y); }
-        }
-    }
-    block_add_stat(&st.stats[ST_SHADOW_RAYS], n_valid);
-    block_add_stat(&st.stats[ST_SHADOW_BLOCKED], n_blocked);
-    if ((threadIdx.x & 63u) == 0) {
-        if (wave_tests[0]) atomicAdd(&st.stats[ST_SHADOW_TESTS_TRI], wave_tests[0]);
-        if (wave_tests[1]) atomicAdd(&st.stats[ST_SHADOW_TESTS_SPH], wave_tests[1]);
-        if (wave_tests[2]) atomicAdd(&st.stats[ST_SHADOW_TESTS_ELL], wave_tests[2]);
-    }
-    if (FILTER) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
+    store_shadow_result<R>(st, s, light_bit, &st.stats[ST_SHADOW_TESTS_ELL], wave_tests);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -874,9 +1034,11 @@ __global__ void __launch_bounds__(BLOCK, 6) k_shadow(DevScene sc, State st, uint
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t n_group, uint32_t last_group) {
     const uint32_t n_rays = st.counts[bounce + 1];
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n_rays) return;
-    const uint32_t s = st.list[(bounce + 1) & 1u][i];
+    const uint32_t base = blockIdx.x * BLOCK;
+    if (base >= n_rays) return;
+    const uint32_t i = base + threadIdx.x;
+    const bool valid = i < n_rays;            // lanes past the end repeat the first ray and store nothing
+    const uint32_t s = st.list[(bounce + 1) & 1u][valid ? i : base];
     const uint32_t id = st.hit_id[s];
     const uint32_t kind = id >> 30, index = id & 0x3FFFFFFFu;
     const float* mat = kind == 0 ? sc.tri_mat : (kind == 1 ? sc.sph_mat : sc.ell_mat);
@@ -891,6 +1053,8 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, State st, uint32_t
     float w[3] = {st.wr[s], st.wg[s], st.wb[s]};
     const V3 to_eye = scale(-1.0f, d);                                    // ray_tracing.cpp:684
     const uint32_t blocked = st.blocked[s];
+    block_add_stat(&st.stats[ST_SHADOW_RAYS], valid ? n_group : 0u);
+    block_add_stat(&st.stats[ST_SHADOW_BLOCKED], valid ? __popc(blocked & (n_group >= 32 ? 0xFFFFFFFFu : ((1u << n_group) - 1u))) : 0);
 
     for (uint32_t g = 0; g < n_group; ++g) {
         if (blocked & (1u << g)) continue;
@@ -916,6 +1080,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, State st, uint32_t
         c[1] += w[1] * (scale_g * (di * m[1] + si * m[4]));
         c[2] += w[2] * (scale_b * (di * m[2] + si * m[5]));
     }
+    if (!valid) return;
     st.cr[s] = c[0]; st.cg[s] = c[1]; st.cb[s] = c[2];
     if (last_group) {
         st.blocked[s] = 0u;
@@ -990,7 +1155,13 @@ Library g_lib;
 #ifndef RT_RAYS_PER_LANE
 #define RT_RAYS_PER_LANE 2
 #endif
+#ifndef RT_RAYS_PER_LANE_EYE
+#define RT_RAYS_PER_LANE_EYE 4
+#endif
 constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;
+// The eye-ray scan executes so few instructions per test that, with 2 rays per lane, the LDS
+// broadcast reads of the records (10 LDS cycles per triangle per wave) become the limit.
+constexpr int RAYS_PER_LANE_EYE = RT_RAYS_PER_LANE_EYE;
 constexpr uint32_t DEFAULT_CHUNK_TILES = 8192;   // 33.5 M samples, 3.1 GB of ray state
 constexpr uint32_t MAX_BOUNCES = 62;
 
@@ -1018,7 +1189,7 @@ uint32_t rank_tiles(const rt_render_params& p) {
 struct rt_scene {
     DevScene dev;
     std::vector<void*> allocations;
-    // pre-test records for rays from the eye, rebuilt when the eye moves (one render at a time per scene)
+    // strip records for rays from the eye, rebuilt when the eye moves (one render at a time per scene)
     mutable float4* eye_records = nullptr;
     mutable float eye[3] = {0, 0, 0};
     mutable bool eye_valid = false;
@@ -1095,13 +1266,13 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     hipStream_t stream = g_lib.stream;
     if (sc.n_tri && scene->eye_records) {
         if (!scene->eye_valid || std::memcmp(scene->eye, cam->eye, sizeof scene->eye) != 0) {
-            hipLaunchKernelGGL(k_prep_origin, dim3(ceil_div(sc.n_tri, BLOCK)), dim3(BLOCK), 0, stream, sc.tri, sc.trif, sc.n_tri,
-                               cam->eye[0], cam->eye[1], cam->eye[2], scene->eye_records);
+            hipLaunchKernelGGL(k_prep_strip, dim3(ceil_div(sc.n_tri, BLOCK)), dim3(BLOCK), 0, stream, sc.tri, sc.n_tri,
+                               cam->eye[0], cam->eye[1], cam->eye[2], sc.origin_bound, 0, scene->eye_records);
             HIP_TRY(hipGetLastError());
             std::memcpy(scene->eye, cam->eye, sizeof scene->eye);
             scene->eye_valid = true;
         }
-        sc.trio = scene->eye_records;
+        sc.strip_eye = scene->eye_records;
     }
     Frame f;
     std::memcpy(f.eye, cam->eye, sizeof f.eye);
@@ -1130,22 +1301,39 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         HIP_TRY(hipMemsetAsync(g_lib.counts, 0, 64 * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(k_primary, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, f, sc, st, first);
         const uint32_t scan_blocks = ceil_div(n_samples, BLOCK * RAYS_PER_LANE);
+        const uint32_t eye_blocks = ceil_div(n_samples, BLOCK * RAYS_PER_LANE_EYE);
+        const uint32_t ray_blocks = n_samples / BLOCK;
         for (uint32_t b = 0; b < depth; ++b) {
             timed(timer, 0, [&] {
-                if (!filter) hipLaunchKernelGGL((k_closest<RAYS_PER_LANE, 0>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-                else if (b == 0 && sc.trio) hipLaunchKernelGGL((k_closest<RAYS_PER_LANE, 2>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-                else hipLaunchKernelGGL((k_closest<RAYS_PER_LANE, 1>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+                if (sc.n_tri) {
+                    if (!filter) hipLaunchKernelGGL((k_closest_tri<RAYS_PER_LANE, 0>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+                    else if (b == 0 && sc.strip_eye) hipLaunchKernelGGL((k_closest_tri<RAYS_PER_LANE_EYE, 2>), dim3(eye_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+                    else hipLaunchKernelGGL((k_closest_tri<RAYS_PER_LANE, 1>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+                }
+                if (sc.n_sph) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+                if (sc.n_ell) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
             });
+            hipLaunchKernelGGL(k_hit, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, st, b);
             if (sc.n_lights == 0) {
-                hipLaunchKernelGGL(k_shade, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, sc, st, b, 0u, 0u, 1u);
+                hipLaunchKernelGGL(k_shade, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, st, b, 0u, 0u, 1u);
             } else {
                 for (uint32_t l0 = 0; l0 < sc.n_lights; l0 += 32) {
                     const uint32_t group = (sc.n_lights - l0 < 32) ? sc.n_lights - l0 : 32;
+                    // the directional light, if it is in this group, is light 0; the rest are point lights
+                    const uint32_t n_dir = (l0 == 0 && sc.has_directional) ? 1u : 0u;
+                    const uint32_t n_pt = group - n_dir;
                     timed(timer, 1, [&] {
-                        if (filter) hipLaunchKernelGGL((k_shadow<RAYS_PER_LANE, true>), dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0);
-                        else hipLaunchKernelGGL((k_shadow<RAYS_PER_LANE, false>), dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0);
+                        if (sc.n_tri) {
+                            if (!filter) hipLaunchKernelGGL((k_shadow_tri<RAYS_PER_LANE, 0>), dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
+                            else {
+                                if (n_dir) hipLaunchKernelGGL((k_shadow_tri<RAYS_PER_LANE, 1>), dim3(scan_blocks, 1), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
+                                if (n_pt) hipLaunchKernelGGL((k_shadow_tri<RAYS_PER_LANE_EYE, 2>), dim3(eye_blocks, n_pt), dim3(BLOCK), 0, stream, sc, st, b, l0 + n_dir, l0);
+                            }
+                        }
+                        if (sc.n_sph) hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
+                        if (sc.n_ell) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
                     });
-                    hipLaunchKernelGGL(k_shade, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, sc, st, b, l0, group, (l0 + group == sc.n_lights) ? 1u : 0u);
+                    hipLaunchKernelGGL(k_shade, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, st, b, l0, group, (l0 + group == sc.n_lights) ? 1u : 0u);
                 }
             }
         }
@@ -1260,11 +1448,24 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     float4 *tri, *trif, *sph, *ell, *ell_light;
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &tri))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &trif))) return fail(rc);
-    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &s->eye_records))) return fail(rc);
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 2, &s->eye_records))) return fail(rc);
+    float4* strip_light;
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 2 * desc->n_point_lights, &strip_light))) return fail(rc);
+    d.strip_light = strip_light;
+    {
+        float b = 0.0f;
+        for (int i = 0; i < 6; ++i) b = std::fmax(b, std::fabs(desc->bounding_box[i]));
+        d.origin_bound = 1.001f * b + 1.0e-3f;
+    }
     if ((rc = upload<float4>(s, nullptr, d.n_sph, &sph))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * 6, &ell))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * desc->n_point_lights, &ell_light))) return fail(rc);
     if (d.n_tri) hipLaunchKernelGGL(k_prep_triangles, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, raw_tri, d.tri_nb, tri, trif);
+    for (uint64_t l = 0; d.n_tri && l < desc->n_point_lights; ++l) {
+        const float* L = desc->point_light_sources + l * 6;
+        hipLaunchKernelGGL(k_prep_strip, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, tri, d.n_tri, L[0], L[1], L[2], d.origin_bound, 1,
+                           strip_light + static_cast<size_t>(l) * d.n_tri * 2);
+    }
     if (d.n_sph) hipLaunchKernelGGL(k_prep_spheres, dim3(ceil_div(d.n_sph, BLOCK)), dim3(BLOCK), 0, stream, raw_sph, d.sph_nb, sph);
     if (d.n_ell) hipLaunchKernelGGL(k_prep_ellipsoids, dim3(ceil_div(d.n_ell, BLOCK)), dim3(BLOCK), 0, stream, raw_inv, raw_fwd, d.ell_nb, ell);
     if (d.n_ell && desc->n_point_lights)
