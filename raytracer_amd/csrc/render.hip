@@ -68,6 +68,7 @@ struct DevScene {
     const float4* trif;  // pre-test records, 4 x float4 per triangle, see pretest_stage1
     const float4* strip_eye;    // strip records (2 x float4 per triangle) for rays from the camera eye, see strip_keeps
     const float4* strip_light;  // [point light][triangle] strip records for shadow rays toward that light
+    const float4* strip_any;    // strip records (3 x float4 per triangle) for rays with their own origin, see strip_keeps_any
     const float4* sph;   // (centre, radius)
     const float4* ell;   // 6 x float4: rows of the inverse transform, rows of the transform
     const float4* ell_light;  // [point light][ellipsoid]: inverse transform applied to the light position
@@ -266,6 +267,23 @@ DEV bool pretest_stage2(const Pre& s, float4 f3) {
 // |d.n| >= tolerance); DESIGN.md "Strip pre-test".  A ray the strip keeps goes on to the
 // two-stage pre-test above and then to the full test.
 // Record: (n, Vs.x) (Vs.y, Vs.z, 0, 0) with Vs = V / kappa; Vs = 0 keeps every ray.
+// The same strip test for a ray with its own origin o, through its Pluecker coordinates
+// (d, m = o x d): with U = w1 x n,
+//     (alpha - 0.5) (d.n) = d.(a x U - 0.5 n) + m.U
+// (expand a_o x (w1 x n) with a_o = a - o), a six-term dot product with per-triangle constants.
+// Record: (n, Ws.x) (Ws.y, Ws.z, Us.x, Us.y) (Us.z, 0, 0, 0), Ws = (a x U - 0.5 n)/kappa, Us = U/kappa
+// (k_prep_strip_any, in double; kappa as for strip_keeps plus the rounding of m and of this form).
+DEV bool strip_keeps_any(V3 d, V3 m, float4 s0, float4 s1, float4 s2) {
+    const float dn = vdot(d, xyz(s0));
+    float x = d.x * s0.w;
+    x = fma_(d.y, s1.x, x);
+    x = fma_(d.z, s1.y, x);
+    x = fma_(m.x, s1.z, x);
+    x = fma_(m.y, s1.w, x);
+    x = fma_(m.z, s2.x, x);
+    return !(__builtin_fabsf(x) > __builtin_fabsf(dn));
+}
+
 DEV bool strip_keeps(V3 d, float4 s0, float4 s1) {
     const float dn = vdot(d, xyz(s0));
     const float x = vdot(d, V3{s0.w, s1.x, s1.y});
@@ -453,6 +471,53 @@ __global__ void __launch_bounds__(BLOCK) k_prep_strip(const float4* __restrict__
     q[1] = make_float4(vs[1], vs[2], 0.0f, 0.0f);
 }
 
+// Strip records for rays with their own origin (strip_keeps_any); origins lie within origin_bound of 0.
+__global__ void __launch_bounds__(BLOCK) k_prep_strip_any(const float4* __restrict__ tri, uint32_t n_tri, float origin_bound, float4* __restrict__ out) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n_tri) return;
+    const float4 t0 = tri[static_cast<size_t>(k) * 4], t1 = tri[static_cast<size_t>(k) * 4 + 1], t2 = tri[static_cast<size_t>(k) * 4 + 2], t3 = tri[static_cast<size_t>(k) * 4 + 3];
+    const double a[3] = {t0.x, t0.y, t0.z}, n[3] = {t0.w, t1.w, t2.w}, ab[3] = {t1.x, t1.y, t1.z}, ac[3] = {t2.x, t2.y, t2.z};
+    const double nn = static_cast<double>(t3.x);
+    auto cross = [](const double* l, const double* r, double* o) { o[0] = l[1] * r[2] - l[2] * r[1]; o[1] = l[2] * r[0] - l[0] * r[2]; o[2] = l[0] * r[1] - l[1] * r[0]; };
+    auto max3 = [](const double* v) { return fmax(fabs(v[0]), fmax(fabs(v[1]), fabs(v[2]))); };
+    auto one3 = [](const double* v) { return fabs(v[0]) + fabs(v[1]) + fabs(v[2]); };
+    auto len3 = [](const double* v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    double w1[3], U[3], W[3];
+    cross(n, ab, w1);
+    for (int i = 0; i < 3; ++i) w1[i] /= nn;
+    cross(w1, n, U);
+    cross(a, U, W);
+    for (int i = 0; i < 3; ++i) W[i] -= 0.5 * n[i];
+    const double eps = 5.9604644775390625e-8;   // 2^-24
+    const double B = origin_bound;
+    const double n_one = one3(n);
+    const double Q = max3(n) * fmax(max3(ab), max3(ac)) / nn;
+    const double edges = len3(ab) + len3(ac);
+    const double reach = max3(a) + B;                                  // |a - o|_inf for any origin
+    const double T = 2.0 * (1.7320508075688772 * reach + edges);       // distance from the origin to any accepted hit, with slack
+    const double tol_eff = 0.999e-4;
+    const double S = B + T + max3(a);
+    double bracket = 48.0 * eps * Q * S + 6.0 * eps * Q * T + eps;     // full test against real arithmetic, reciprocal-free t
+    bracket += eps * (7.0 * one3(W) + 18.0 * B * one3(U)               // rounding of the six-term product and of m = o x d
+                      + 24.0 * Q * n_one * reach                        // rounding of (a - o).n in the full test
+                      + 3.0 * (6.0 * Q * reach + 0.5) * n_one) / tol_eff;   // rounding of d.n
+    const double kappa = 0.5 + 2.0 * bracket;
+    float ws[3] = {0.0f, 0.0f, 0.0f}, us[3] = {0.0f, 0.0f, 0.0f};
+    if (nn > 0.0 && kappa < 1.0e30) {
+        bool ok = true;
+        for (int i = 0; i < 3; ++i) {
+            ws[i] = static_cast<float>(W[i] / kappa);
+            us[i] = static_cast<float>(U[i] / kappa);
+            ok = ok && fabsf(ws[i]) < 1.0e30f && fabsf(us[i]) < 1.0e30f;
+        }
+        if (!ok) for (int i = 0; i < 3; ++i) ws[i] = us[i] = 0.0f;
+    }
+    float4* q = out + static_cast<size_t>(k) * 3;
+    q[0] = make_float4(static_cast<float>(n[0]), static_cast<float>(n[1]), static_cast<float>(n[2]), ws[0]);
+    q[1] = make_float4(ws[1], ws[2], us[0], us[1]);
+    q[2] = make_float4(us[2], 0.0f, 0.0f, 0.0f);
+}
+
 __global__ void __launch_bounds__(BLOCK) k_prep_spheres(const float* __restrict__ sph8, uint32_t nb, float4* __restrict__ out) {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= 8u * nb) return;
@@ -575,10 +640,12 @@ DEV void load_rays(const State& st, const uint32_t* __restrict__ list_in, uint32
 }
 
 // MODE 0: every triangle through the full test; 1: two-stage pre-test first;
-// 2: strip pre-test (rays from the eye, bounce 0), then the two-stage pre-test, then the full test
+// 2: strip pre-test (rays from the eye, bounce 0), then the two-stage pre-test, then the full test;
+// 3: the same with the strip pre-test for rays with their own origin
 template <int R, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, uint32_t bounce) {
-    __shared__ float4 lds[TILE_PRIMS * (MODE == 2 ? 2 : 4)];
+    constexpr int WORDS = MODE == 2 ? 2 : (MODE == 3 ? 3 : 4);
+    __shared__ float4 lds[TILE_PRIMS * WORDS];
     const uint32_t n_rays = st.counts[bounce];
     const uint32_t base = blockIdx.x * (BLOCK * R);
     if (base >= n_rays) return;
@@ -596,11 +663,17 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
         best_t[r] = FLT_MAX; best_k[r] = 0xFFFFFFFFu;
         o_max[r] = fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z)));
     }
-    const float4* __restrict__ tri_stream = MODE == 2 ? sc.strip_eye : (MODE == 1 ? sc.trif : sc.tri);
+    V3 moment[R];   // MODE 3: o x d, NaN where the strip test must not reject
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        moment[r] = scross(o[r], d[r]);
+        if (!(o_max[r] <= sc.origin_bound)) moment[r].x = __builtin_nanf("");
+    }
+    const float4* __restrict__ tri_stream = MODE == 2 ? sc.strip_eye : (MODE == 3 ? sc.strip_any : (MODE == 1 ? sc.trif : sc.tri));
     for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
         __syncthreads();
-        stage_tile<(MODE == 2 ? 2 : 4)>(lds, tri_stream, first, count);
+        stage_tile<WORDS>(lds, tri_stream, first, count);
         __syncthreads();
         auto full_test = [&](uint32_t k) {
             // some lane may hit: the whole wave runs the full test on the full record
@@ -613,12 +686,18 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
             }
             n_full += R;
         };
-        if (MODE == 2) {
+        if (MODE == 2 || MODE == 3) {
             for (uint32_t k = 0; k < count; ++k) {
-                const float4 s0 = lds[k * 2], s1 = lds[k * 2 + 1];
                 bool keep = false;
+                if (MODE == 2) {
+                    const float4 s0 = lds[k * 2], s1 = lds[k * 2 + 1];
 #pragma unroll
-                for (int r = 0; r < R; ++r) keep |= strip_keeps(d[r], s0, s1);
+                    for (int r = 0; r < R; ++r) keep |= strip_keeps(d[r], s0, s1);
+                } else {
+                    const float4 s0 = lds[k * 3], s1 = lds[k * 3 + 1], s2 = lds[k * 3 + 2];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) keep |= strip_keeps_any(d[r], moment[r], s0, s1, s2);
+                }
                 if (__any(keep)) {
                     const float4* __restrict__ f = sc.trif + static_cast<size_t>(first + k) * 4;
                     const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
@@ -867,11 +946,13 @@ DEV void store_shadow_result(const State& st, const ShadowRays<R>& s, uint32_t l
 }
 
 // MODE 0: full test only; 1: two-stage pre-test; 2: strip pre-test first (point lights only:
-// lights first_light.. are point lights and their strip records start at sc.strip_light)
+// lights first_light.. are point lights and their strip records start at sc.strip_light);
+// 3: strip pre-test for rays with their own origin (any light)
 template <int R, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
     constexpr bool FILTER = MODE != 0;
-    __shared__ float4 lds[TILE_PRIMS * (MODE == 2 ? 2 : 4)];
+    constexpr int WORDS = MODE == 2 ? 2 : (MODE == 3 ? 3 : 4);
+    __shared__ float4 lds[TILE_PRIMS * WORDS];
     const uint32_t n_rays = st.counts[bounce + 1];
     const uint32_t base = blockIdx.x * (BLOCK * R);
     if (base >= n_rays) return;
@@ -886,7 +967,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         o_max[r] = fmaxf(fabsf(s.o[r].x), fmaxf(fabsf(s.o[r].y), fabsf(s.o[r].z)));
-        line[r] = sub(lv, s.o[r]);
+        line[r] = MODE == 3 ? scross(s.o[r], s.d[r]) : sub(lv, s.o[r]);   // MODE 3: the ray's moment o x d
         if (!(o_max[r] <= sc.origin_bound)) line[r].x = __builtin_nanf("");
     }
 
@@ -894,20 +975,26 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
     uint32_t n_full = 0;
     bool done = shadow_wave_done<R>(s);
     const float4* __restrict__ tri_stream = MODE == 2 ? sc.strip_light + static_cast<size_t>(light - sc.has_directional) * sc.n_tri * 2
-                                                      : (MODE == 1 ? sc.trif : sc.tri);
+                                                      : (MODE == 3 ? sc.strip_any : (MODE == 1 ? sc.trif : sc.tri));
     for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
         if (__syncthreads_and(done)) break;
-        stage_tile<(MODE == 2 ? 2 : 4)>(lds, tri_stream, first, count);
+        stage_tile<WORDS>(lds, tri_stream, first, count);
         __syncthreads();
         if (!done) {
             wave_tests += shadow_live_tests<R>(s, count);
-            if (MODE == 2) {
+            if (MODE == 2 || MODE == 3) {
                 for (uint32_t k = 0; k < count; ++k) {
-                    const float4 s0 = lds[k * 2], s1 = lds[k * 2 + 1];
                     bool keep = false;
+                    if (MODE == 2) {
+                        const float4 s0 = lds[k * 2], s1 = lds[k * 2 + 1];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) keep |= strip_keeps(line[r], s0, s1);
+                        for (int r = 0; r < R; ++r) keep |= strip_keeps(line[r], s0, s1);
+                    } else {
+                        const float4 s0 = lds[k * 3], s1 = lds[k * 3 + 1], s2 = lds[k * 3 + 2];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) keep |= strip_keeps_any(s.d[r], line[r], s0, s1, s2);
+                    }
                     if (__any(keep)) {
                         const float4* __restrict__ f = sc.trif + static_cast<size_t>(first + k) * 4;
                         const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
@@ -1308,7 +1395,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                 if (sc.n_tri) {
                     if (!filter) hipLaunchKernelGGL((k_closest_tri<RAYS_PER_LANE, 0>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
                     else if (b == 0 && sc.strip_eye) hipLaunchKernelGGL((k_closest_tri<RAYS_PER_LANE_EYE, 2>), dim3(eye_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-                    else hipLaunchKernelGGL((k_closest_tri<RAYS_PER_LANE, 1>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+                    else hipLaunchKernelGGL((k_closest_tri<RAYS_PER_LANE_EYE, 3>), dim3(eye_blocks), dim3(BLOCK), 0, stream, sc, st, b);
                 }
                 if (sc.n_sph) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
                 if (sc.n_ell) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
@@ -1326,7 +1413,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                         if (sc.n_tri) {
                             if (!filter) hipLaunchKernelGGL((k_shadow_tri<RAYS_PER_LANE, 0>), dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
                             else {
-                                if (n_dir) hipLaunchKernelGGL((k_shadow_tri<RAYS_PER_LANE, 1>), dim3(scan_blocks, 1), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
+                                if (n_dir) hipLaunchKernelGGL((k_shadow_tri<RAYS_PER_LANE_EYE, 3>), dim3(eye_blocks, 1), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
                                 if (n_pt) hipLaunchKernelGGL((k_shadow_tri<RAYS_PER_LANE_EYE, 2>), dim3(eye_blocks, n_pt), dim3(BLOCK), 0, stream, sc, st, b, l0 + n_dir, l0);
                             }
                         }
@@ -1449,9 +1536,11 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &tri))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &trif))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 2, &s->eye_records))) return fail(rc);
-    float4* strip_light;
+    float4 *strip_light, *strip_any;
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 2 * desc->n_point_lights, &strip_light))) return fail(rc);
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 3, &strip_any))) return fail(rc);
     d.strip_light = strip_light;
+    d.strip_any = strip_any;
     {
         float b = 0.0f;
         for (int i = 0; i < 6; ++i) b = std::fmax(b, std::fabs(desc->bounding_box[i]));
@@ -1461,6 +1550,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * 6, &ell))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * desc->n_point_lights, &ell_light))) return fail(rc);
     if (d.n_tri) hipLaunchKernelGGL(k_prep_triangles, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, raw_tri, d.tri_nb, tri, trif);
+    if (d.n_tri) hipLaunchKernelGGL(k_prep_strip_any, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, tri, d.n_tri, d.origin_bound, strip_any);
     for (uint64_t l = 0; d.n_tri && l < desc->n_point_lights; ++l) {
         const float* L = desc->point_light_sources + l * 6;
         hipLaunchKernelGGL(k_prep_strip, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, tri, d.n_tri, L[0], L[1], L[2], d.origin_bound, 1,
