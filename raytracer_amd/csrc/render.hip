@@ -66,8 +66,8 @@ constexpr uint32_t SAMPLES_PER_TILE = RT_TILE * RT_TILE * RT_SAMPLES_PER_PIXEL; 
 struct DevScene {
     const float4* tri;   // 4 x float4 per triangle: (a, n.x) (a_to_b, n.y) (a_to_c, n.z) (n.n, 0, 0, 0)
     const float4* trif;  // pre-test records, 4 x float4 per triangle, see pretest_stage1
-    const float4* strip_eye;    // strip records (2 x float4 per triangle) for rays from the camera eye, see strip_keeps
-    const float4* strip_light;  // [point light][triangle] strip records for shadow rays toward that light
+    const float4* cone_eye;     // cone records (1 x float4 per triangle) for rays from the camera eye, see cone_keeps
+    const float4* cone_light;   // [point light][triangle] cone records for shadow rays toward that light
     const float4* strip_any;    // strip records (3 x float4 per triangle) for rays with their own origin, see strip_keeps_any
     const float4* sph;   // (centre, radius)
     const float4* ell;   // 6 x float4: rows of the inverse transform, rows of the transform
@@ -255,24 +255,26 @@ DEV bool pretest_stage2(const Pre& s, float4 f3) {
     return !(u < 0.5f - s.thr);
 }
 
-// Strip pre-test for rays that pass through one common point X: camera rays (X = eye) and
-// shadow rays toward a point light (X = light position; the line is the same whichever end it
-// is walked from).  For such rays (a - X), num = (a - X).n and c1 = w1.(a - X) are per-triangle
-// constants, and with alpha = t (w1.d) - c1, t = num / (d.n):
-//     (alpha - 0.5) (d.n) = V.d,   V = num w1 - (c1 + 0.5) n        (a per-triangle vector)
-// so "alpha is outside [-2m, 1 + 2m]" becomes |V.d| > kappa |d.n| with kappa = 0.5 + 2m.  The
-// record holds n and V / kappa (k_prep_strip, computed in double): two dot products and one
-// compare per ray and triangle, no reciprocal.  kappa also covers the rounding of this form,
-// including the terms that do not scale with |d.n| (bounded through the full test's own
-// |d.n| >= tolerance); DESIGN.md "Strip pre-test".  A ray the strip keeps goes on to the
-// two-stage pre-test above and then to the full test.
-// Record: (n, Vs.x) (Vs.y, Vs.z, 0, 0) with Vs = V / kappa; Vs = 0 keeps every ray.
-// The same strip test for a ray with its own origin o, through its Pluecker coordinates
-// (d, m = o x d): with U = w1 x n,
-//     (alpha - 0.5) (d.n) = d.(a x U - 0.5 n) + m.U
-// (expand a_o x (w1 x n) with a_o = a - o), a six-term dot product with per-triangle constants.
+// Cone pre-test for rays that pass through one common point X: camera rays (X = eye) and
+// shadow rays toward a point light (X = light position).  Seen from X, a triangle (inflated by
+// the margin m of the two-stage pre-test, and for shadow rays by the rounding of the direction
+// (X - origin)/|X - origin| that the full test uses) lies inside a cone of directions around an
+// axis; a unit direction d outside that cone cannot hit it.  One dot product and one compare
+// per ray and triangle.  The record (k_prep_cone, in double) is (axis, cos(half angle)) with the
+// cosine lowered by the rounding of d.axis; cos = -2 keeps every ray.  NaN keeps the ray.
+DEV bool cone_keeps(V3 d, float4 c) { return !(vdot(d, xyz(c)) < c.w); }
+
+// Strip pre-test for a ray with its own origin o.  With num = (a - o).n, c1 = w1.(a - o),
+// alpha = t (w1.d) - c1 and t = num / (d.n):
+//     (alpha - 0.5) (d.n) = V.d,   V = num w1 - (c1 + 0.5) n,
+// so "alpha is outside [-2m, 1 + 2m]" becomes |V.d| > kappa |d.n| with kappa = 0.5 + 2m, and no
+// reciprocal is needed.  In the ray's Pluecker coordinates (d, m = o x d), with U = w1 x n,
+//     V.d = d.(a x U - 0.5 n) + m.U
+// (expand (a - o) x (w1 x n)), a six-term dot product with per-triangle constants.
 // Record: (n, Ws.x) (Ws.y, Ws.z, Us.x, Us.y) (Us.z, 0, 0, 0), Ws = (a x U - 0.5 n)/kappa, Us = U/kappa
-// (k_prep_strip_any, in double; kappa as for strip_keeps plus the rounding of m and of this form).
+// (k_prep_strip_any, in double).  kappa also covers the rounding of m and of this form, including
+// the terms that do not scale with |d.n| (bounded through the full test's own |d.n| >= tolerance);
+// DESIGN.md "Strip pre-test".  Ws = Us = 0 keeps every ray.
 DEV bool strip_keeps_any(V3 d, V3 m, float4 s0, float4 s1, float4 s2) {
     const float dn = vdot(d, xyz(s0));
     float x = d.x * s0.w;
@@ -281,12 +283,6 @@ DEV bool strip_keeps_any(V3 d, V3 m, float4 s0, float4 s1, float4 s2) {
     x = fma_(m.x, s1.z, x);
     x = fma_(m.y, s1.w, x);
     x = fma_(m.z, s2.x, x);
-    return !(__builtin_fabsf(x) > __builtin_fabsf(dn));
-}
-
-DEV bool strip_keeps(V3 d, float4 s0, float4 s1) {
-    const float dn = vdot(d, xyz(s0));
-    const float x = vdot(d, V3{s0.w, s1.x, s1.y});
     return !(__builtin_fabsf(x) > __builtin_fabsf(dn));
 }
 
@@ -420,55 +416,79 @@ __global__ void __launch_bounds__(BLOCK) k_prep_triangles(const float* __restric
     q[3] = make_float4(w2.x, w2.y, w2.z, 0.0f);
 }
 
-// Strip records (strip_keeps) for lines through X.  `reversed` = 1: X is a point light and the
-// full test walks the line from the other end (origin within origin_bound of 0, unit direction
-// rounded from (X - origin)); 0: X is the camera eye and the full test starts at X itself.
-// Everything is evaluated in double from the binary32 data; only a - X and (a - X).n are
-// taken in binary32, as the full test computes them.
-__global__ void __launch_bounds__(BLOCK) k_prep_strip(const float4* __restrict__ tri, uint32_t n_tri, float x, float y, float z,
-                                                      float origin_bound, int reversed, float4* __restrict__ out) {
+// Cone records (cone_keeps) for rays through X.  `reversed` = 0: X is the camera eye, the full
+// test starts at X with the unit direction d that is also tested here.  `reversed` = 1: X is a
+// point light; the full test starts at an origin within origin_bound of 0 with the rounded unit
+// direction d toward X, and the axis stored is the one d itself has to be close to.
+// All in double.  Let m bound the barycentric error of the full test (as in the two-stage
+// pre-test, with |t| bounded by the distance to the farthest point of the triangle): whenever
+// the full test accepts, its hit point lies within delta of the triangle scaled by (1 + 3m)
+// about its centroid, where delta covers the hit point being slightly off the plane and, for
+// shadow rays, the rounding of the direction.  The cone is the one around the direction to the
+// centroid that contains the three scaled vertices, widened by asin(delta / distance).
+__global__ void __launch_bounds__(BLOCK) k_prep_cone(const float4* __restrict__ tri, uint32_t n_tri, float x, float y, float z,
+                                                     float origin_bound, int reversed, float4* __restrict__ out) {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= n_tri) return;
     const float4 t0 = tri[static_cast<size_t>(k) * 4], t1 = tri[static_cast<size_t>(k) * 4 + 1], t2 = tri[static_cast<size_t>(k) * 4 + 2], t3 = tri[static_cast<size_t>(k) * 4 + 3];
-    const V3 a32 = xyz(t0), n32{t0.w, t1.w, t2.w};
-    const V3 ax32 = sub(a32, V3{x, y, z});
-    const double num = static_cast<double>(vdot(ax32, n32));
-    const double n[3] = {n32.x, n32.y, n32.z}, ab[3] = {t1.x, t1.y, t1.z}, ac[3] = {t2.x, t2.y, t2.z};
-    const double ax[3] = {ax32.x, ax32.y, ax32.z}, a[3] = {a32.x, a32.y, a32.z};
+    const double a[3] = {t0.x, t0.y, t0.z}, n[3] = {t0.w, t1.w, t2.w}, ab[3] = {t1.x, t1.y, t1.z}, ac[3] = {t2.x, t2.y, t2.z};
+    const double X[3] = {x, y, z};
     const double nn = static_cast<double>(t3.x);
-    const double w1[3] = {(n[1] * ab[2] - n[2] * ab[1]) / nn, (n[2] * ab[0] - n[0] * ab[2]) / nn, (n[0] * ab[1] - n[1] * ab[0]) / nn};
-    const double c1 = w1[0] * ax[0] + w1[1] * ax[1] + w1[2] * ax[2];
     auto max3 = [](const double* v) { return fmax(fabs(v[0]), fmax(fabs(v[1]), fabs(v[2]))); };
     auto len3 = [](const double* v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    float4 rec = make_float4(0.0f, 0.0f, 0.0f, -2.0f);   // keeps every ray
     const double eps = 5.9604644775390625e-8;   // 2^-24
-    const double n_max = max3(n), n_one = fabs(n[0]) + fabs(n[1]) + fabs(n[2]);
-    const double Q = n_max * fmax(max3(ab), max3(ac)) / nn;
+    const double n_one = fabs(n[0]) + fabs(n[1]) + fabs(n[2]);
     const double edges = len3(ab) + len3(ac);
-    const double T_x = 2.0 * (len3(ax) + edges);                      // distance from X to any accepted hit, with slack
-    const double x_max = fmax(fabs(static_cast<double>(x)), fmax(fabs(static_cast<double>(y)), fabs(static_cast<double>(z))));
-    const double tol = 1.0e-4;
-    double tol_eff, S, bracket;
-    if (reversed) {
-        const double B = origin_bound;
-        const double T_p = 2.0 * (1.7320508075688772 * (max3(a) + B) + edges);   // distance from the full test's origin to the hit
-        tol_eff = tol - 8.0 * eps * n_one;
-        S = B + T_p + max3(a);
-        bracket = 48.0 * eps * Q * S + 12.0 * eps * Q * T_x + eps + 12.0 * eps * Q * T_p * (1.0 + n_one / tol_eff) + 6.0 * eps * Q * max3(ax);
-    } else {
-        tol_eff = 0.999 * tol;
-        S = x_max + T_x + max3(a);
-        bracket = 48.0 * eps * Q * S + 6.0 * eps * Q * T_x + eps;
+    double ax[3], c[3], v[3][3];
+    for (int i = 0; i < 3; ++i) {
+        ax[i] = a[i] - X[i];
+        c[i] = a[i] + (ab[i] + ac[i]) / 3.0;
+        v[0][i] = a[i]; v[1][i] = a[i] + ab[i]; v[2][i] = a[i] + ac[i];
     }
-    bracket += eps * n_max * (198.0 * Q * max3(ax) + 11.0) / tol_eff;
-    const double kappa = (0.5 + 2.0 * bracket) * (1.0 + 4.0 * eps * n_one / tol_eff);
-    float vs[3] = {0.0f, 0.0f, 0.0f};
-    if (nn > 0.0 && tol_eff > 2.0e-5 && kappa < 1.0e30) {   // also false for NaN
-        for (int i = 0; i < 3; ++i) vs[i] = static_cast<float>((num * w1[i] - (c1 + 0.5) * n[i]) / kappa);
-        if (!(fabsf(vs[0]) < 1.0e30f && fabsf(vs[1]) < 1.0e30f && fabsf(vs[2]) < 1.0e30f)) vs[0] = vs[1] = vs[2] = 0.0f;
+    if (nn > 0.0) {
+        const double Q = max3(n) * fmax(max3(ab), max3(ac)) / nn;
+        double m, delta;
+        bool usable = true;
+        if (reversed) {
+            const double B = origin_bound;
+            const double T_p = 2.0 * (1.7320508075688772 * (max3(a) + B) + edges);   // origin of the full test to the hit
+            const double tol_eff = 1.0e-4 - 8.0 * eps * n_one;
+            usable = tol_eff > 2.0e-5;
+            m = 2.0 * (48.0 * eps * Q * (B + T_p + max3(a)) + eps);
+            delta = 2.0 * (13.0 * eps * T_p + 4.0 * eps * T_p);
+        } else {
+            const double T_x = 2.0 * (len3(ax) + edges);
+            m = 2.0 * (48.0 * eps * Q * (max3(X) + T_x + max3(a)) + eps);
+            delta = 2.0 * 13.0 * eps * T_x;
+        }
+        double axis[3], to_c[3];
+        for (int i = 0; i < 3; ++i) to_c[i] = c[i] - X[i];
+        const double dist_c = len3(to_c);
+        double cos_min = 1.0, r_b = 0.0;
+        bool ok = usable && dist_c > 0.0 && m < 1.0e6;
+        for (int i = 0; i < 3 && ok; ++i) axis[i] = to_c[i] / dist_c;
+        for (int j = 0; j < 3 && ok; ++j) {
+            double w[3], out_c[3];
+            for (int i = 0; i < 3; ++i) { out_c[i] = (1.0 + 3.0 * m) * (v[j][i] - c[i]); w[i] = c[i] + out_c[i] - X[i]; }
+            const double lw = len3(w);
+            r_b = fmax(r_b, len3(out_c));
+            if (!(lw > 0.0)) { ok = false; break; }
+            cos_min = fmin(cos_min, (w[0] * axis[0] + w[1] * axis[1] + w[2] * axis[2]) / lw);
+        }
+        const double d_min = dist_c - r_b - delta;
+        if (ok && d_min > 4.0 * delta && cos_min > -1.0) {
+            const double theta = acos(fmin(1.0, cos_min)) + asin(delta / d_min);
+            if (theta < 1.5) {
+                const double cos_store = cos(theta) * (1.0 - 8.0 * eps) - 16.0 * eps;
+                const double sign = reversed ? -1.0 : 1.0;
+                rec = make_float4(static_cast<float>(sign * axis[0]), static_cast<float>(sign * axis[1]), static_cast<float>(sign * axis[2]),
+                                  nextafterf(static_cast<float>(cos_store), -2.0f));
+                if (!(rec.w > -1.0f && rec.w < 1.0f)) rec = make_float4(0.0f, 0.0f, 0.0f, -2.0f);
+            }
+        }
     }
-    float4* q = out + static_cast<size_t>(k) * 2;
-    q[0] = make_float4(n32.x, n32.y, n32.z, vs[0]);
-    q[1] = make_float4(vs[1], vs[2], 0.0f, 0.0f);
+    out[k] = rec;
 }
 
 // Strip records for rays with their own origin (strip_keeps_any); origins lie within origin_bound of 0.
@@ -639,91 +659,74 @@ DEV void load_rays(const State& st, const uint32_t* __restrict__ list_in, uint32
     }
 }
 
-// MODE 0: every triangle through the full test; 1: two-stage pre-test first;
-// 2: strip pre-test (rays from the eye, bounce 0), then the two-stage pre-test, then the full test;
-// 3: the same with the strip pre-test for rays with their own origin
+// What follows a wave-uniform first pre-test that kept some lane: the two-stage pre-test on the
+// generic record, and the full test if that keeps some lane too.  Returns whether the full test ran;
+// t[r] then holds its result for ray r.
+template <int R>
+DEV bool pretests_then_full(const DevScene& sc, uint32_t k, const V3 (&o)[R], const V3 (&d)[R], float (&t)[R]) {
+    const float4* __restrict__ f = sc.trif + static_cast<size_t>(k) * 4;
+    const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
+    bool keep = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        Pre pre;
+        const float o_max = fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z)));
+        keep |= pretest_stage1(o[r], d[r], o_max, f0, f1, f2, pre) && pretest_stage2(pre, f3);
+    }
+    if (!__any(keep)) return false;
+    const float4* __restrict__ rec = sc.tri + static_cast<size_t>(k) * 4;
+    const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3];
+#pragma unroll
+    for (int r = 0; r < R; ++r) t[r] = hit_triangle(o[r], d[r], e0, e1, e2, e3.x);
+    return true;
+}
+
+// MODE 0: every triangle through the full test (RT_FLAG_NO_FILTER);
+// 2: cone pre-test for rays from the eye (bounce 0); 3: strip pre-test for rays with their own origin.
+// A triangle that the first pre-test keeps for some lane of the wave goes through
+// pretests_then_full.  In modes 2 and 3 only the direction (and moment) of a ray stays in
+// registers during the scan; origins are re-read when a triangle is kept.
 template <int R, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, uint32_t bounce) {
-    constexpr int WORDS = MODE == 2 ? 2 : (MODE == 3 ? 3 : 4);
+    constexpr int WORDS = MODE == 2 ? 1 : (MODE == 3 ? 3 : 4);
     __shared__ float4 lds[TILE_PRIMS * WORDS];
     const uint32_t n_rays = st.counts[bounce];
     const uint32_t base = blockIdx.x * (BLOCK * R);
     if (base >= n_rays) return;
+    const uint32_t* __restrict__ list_in = st.list[bounce & 1u];
 
     uint32_t slot[R];
     bool valid[R];
-    V3 o[R], d[R];
-    load_rays<R>(st, st.list[bounce & 1u], base, n_rays, slot, valid, o, d);
-
+    V3 d[R], moment[R];
     float best_t[R]; uint32_t best_k[R];
-    float o_max[R];   // pre-test only: |o|_inf
-    uint32_t n_full = 0;
+    bool unsafe = false;    // an origin outside the bound the strip records were built for: keep everything
 #pragma unroll
     for (int r = 0; r < R; ++r) {
+        const uint32_t i = base + r * BLOCK + threadIdx.x;
+        valid[r] = i < n_rays;
+        slot[r] = list_in[valid[r] ? i : base];
+        const V3 o{st.ox[slot[r]], st.oy[slot[r]], st.oz[slot[r]]};
+        d[r] = {st.dx[slot[r]], st.dy[slot[r]], st.dz[slot[r]]};
+        moment[r] = scross(o, d[r]);
+        unsafe |= !(fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))) <= sc.origin_bound);
         best_t[r] = FLT_MAX; best_k[r] = 0xFFFFFFFFu;
-        o_max[r] = fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z)));
     }
-    V3 moment[R];   // MODE 3: o x d, NaN where the strip test must not reject
+    const bool keep_all = MODE == 3 && __any(unsafe);
+    uint32_t n_full = 0;
+
+    auto origins = [&](V3 (&o)[R]) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        moment[r] = scross(o[r], d[r]);
-        if (!(o_max[r] <= sc.origin_bound)) moment[r].x = __builtin_nanf("");
-    }
-    const float4* __restrict__ tri_stream = MODE == 2 ? sc.strip_eye : (MODE == 3 ? sc.strip_any : (MODE == 1 ? sc.trif : sc.tri));
+        for (int r = 0; r < R; ++r) o[r] = {st.ox[slot[r]], st.oy[slot[r]], st.oz[slot[r]]};
+    };
+    const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_eye : (MODE == 3 ? sc.strip_any : sc.tri);
     for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
         __syncthreads();
         stage_tile<WORDS>(lds, tri_stream, first, count);
         __syncthreads();
-        auto full_test = [&](uint32_t k) {
-            // some lane may hit: the whole wave runs the full test on the full record
-            const float4* __restrict__ rec = sc.tri + static_cast<size_t>(first + k) * 4;
-            const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float t = hit_triangle(o[r], d[r], e0, e1, e2, e3.x);
-                if (t < best_t[r]) { best_t[r] = t; best_k[r] = first + k; }
-            }
-            n_full += R;
-        };
-        if (MODE == 2 || MODE == 3) {
-            for (uint32_t k = 0; k < count; ++k) {
-                bool keep = false;
-                if (MODE == 2) {
-                    const float4 s0 = lds[k * 2], s1 = lds[k * 2 + 1];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) keep |= strip_keeps(d[r], s0, s1);
-                } else {
-                    const float4 s0 = lds[k * 3], s1 = lds[k * 3 + 1], s2 = lds[k * 3 + 2];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) keep |= strip_keeps_any(d[r], moment[r], s0, s1, s2);
-                }
-                if (__any(keep)) {
-                    const float4* __restrict__ f = sc.trif + static_cast<size_t>(first + k) * 4;
-                    const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
-                    Pre pre[R];
-                    keep = false;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) keep |= pretest_stage1(o[r], d[r], o_max[r], f0, f1, f2, pre[r]) && pretest_stage2(pre[r], f3);
-                    if (__any(keep)) full_test(k);
-                }
-            }
-        } else if (MODE == 1) {
-            for (uint32_t k = 0; k < count; ++k) {
-                const float4 f0 = lds[k * 4], f1 = lds[k * 4 + 1], f2 = lds[k * 4 + 2];
-                Pre pre[R];
-                bool keep = false;
-#pragma unroll
-                for (int r = 0; r < R; ++r) keep |= pretest_stage1(o[r], d[r], o_max[r], f0, f1, f2, pre[r]);
-                if (__any(keep)) {
-                    const float4 f3 = lds[k * 4 + 3];
-                    keep = false;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) keep |= pretest_stage2(pre[r], f3);
-                    if (__any(keep)) full_test(k);
-                }
-            }
-        } else {
+        if (MODE == 0) {
+            V3 o[R];
+            origins(o);
 #pragma unroll 2
             for (uint32_t k = 0; k < count; ++k) {
                 const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
@@ -731,6 +734,29 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
                 for (int r = 0; r < R; ++r) {
                     const float t = hit_triangle(o[r], d[r], t0, t1, t2, t3.x);
                     if (t < best_t[r]) { best_t[r] = t; best_k[r] = first + k; }
+                }
+            }
+        } else {
+            for (uint32_t k = 0; k < count; ++k) {
+                bool keep = keep_all;
+                if (MODE == 2) {
+                    const float4 c = lds[k];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) keep |= cone_keeps(d[r], c);
+                } else {
+                    const float4 s0 = lds[k * 3], s1 = lds[k * 3 + 1], s2 = lds[k * 3 + 2];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) keep |= strip_keeps_any(d[r], moment[r], s0, s1, s2);
+                }
+                if (__any(keep)) {
+                    V3 o[R];
+                    float t[R];
+                    origins(o);
+                    if (pretests_then_full<R>(sc, first + k, o, d, t)) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) if (t[r] < best_t[r]) { best_t[r] = t[r]; best_k[r] = first + k; }
+                        n_full += R;
+                    }
                 }
             }
         }
@@ -945,106 +971,128 @@ DEV void store_shadow_result(const State& st, const ShadowRays<R>& s, uint32_t l
     if ((threadIdx.x & 63u) == 0 && wave_tests) atomicAdd(stat, wave_tests);
 }
 
-// MODE 0: full test only; 1: two-stage pre-test; 2: strip pre-test first (point lights only:
-// lights first_light.. are point lights and their strip records start at sc.strip_light);
-// 3: strip pre-test for rays with their own origin (any light)
+// One shadow ray: origin above the surface (ray_tracing.cpp:685-686), direction and limit per
+// light kind (:350-354 point, :410-412 directional).  Deterministic, so it can be rebuilt on demand.
+struct ShadowRay { V3 o, d; float limit; };
+DEV ShadowRay make_shadow_ray(const State& st, uint32_t slot, bool point, V3 lv) {
+    ShadowRay s;
+    const V3 p{st.px[slot], st.py[slot], st.pz[slot]};
+    const V3 n{st.nx[slot], st.ny[slot], st.nz[slot]};
+    s.o = add(p, scale(2.0f * TOL, n));
+    if (point) {
+        const V3 to_light = sub(lv, s.o);
+        s.limit = sqrt_(sdot(to_light, to_light));
+        const float inv = 1.0f / s.limit;
+        s.d = scale(inv, to_light);
+    } else {
+        s.d = scale(-1.0f, lv);
+        s.limit = FLT_MAX;
+    }
+    return s;
+}
+
+// MODE 0: full test only; 2: cone pre-test (point lights only: lights first_light.. are point
+// lights, their cone records start at sc.cone_light); 3: strip pre-test for rays with their own
+// origin (any light).  As in k_closest_tri only the direction (and moment) stays in registers.
 template <int R, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
-    constexpr bool FILTER = MODE != 0;
-    constexpr int WORDS = MODE == 2 ? 2 : (MODE == 3 ? 3 : 4);
+    constexpr int WORDS = MODE == 2 ? 1 : (MODE == 3 ? 3 : 4);
     __shared__ float4 lds[TILE_PRIMS * WORDS];
     const uint32_t n_rays = st.counts[bounce + 1];
     const uint32_t base = blockIdx.x * (BLOCK * R);
     if (base >= n_rays) return;
+    const uint32_t* __restrict__ list_in = st.list[(bounce + 1) & 1u];
     const uint32_t light = first_light + blockIdx.y;
     const float* __restrict__ L = sc.lights + light * 8;
     const uint32_t light_bit = 1u << (light - group_first);
+    const bool point = L[0] != 0.0f;
     const V3 lv{L[1], L[2], L[3]};
-    ShadowRays<R> s;
-    load_shadow_rays<R>(st, st.list[(bounce + 1) & 1u], base, n_rays, L[0] != 0.0f, lv, light_bit, s);
-    float o_max[R];
-    V3 line[R];   // MODE 2: un-normalised direction of the line through the light, NaN where the strip test must not reject
+
+    uint32_t slot[R];
+    bool valid[R], blocked[R];
+    V3 d[R], moment[R];
+    bool unsafe = false;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        o_max[r] = fmaxf(fabsf(s.o[r].x), fmaxf(fabsf(s.o[r].y), fabsf(s.o[r].z)));
-        line[r] = MODE == 3 ? scross(s.o[r], s.d[r]) : sub(lv, s.o[r]);   // MODE 3: the ray's moment o x d
-        if (!(o_max[r] <= sc.origin_bound)) line[r].x = __builtin_nanf("");
+        const uint32_t i = base + r * BLOCK + threadIdx.x;
+        valid[r] = i < n_rays;
+        slot[r] = list_in[valid[r] ? i : base];
+        const ShadowRay s = make_shadow_ray(st, slot[r], point, lv);
+        d[r] = s.d;
+        moment[r] = scross(s.o, s.d);
+        unsafe |= !(fmaxf(fabsf(s.o.x), fmaxf(fabsf(s.o.y), fabsf(s.o.z))) <= sc.origin_bound);
+        blocked[r] = (st.blocked[slot[r]] & light_bit) != 0u;
     }
+    const bool keep_all = MODE != 0 && __any(unsafe);
+    auto wave_done = [&]() {
+        bool all = true;
+#pragma unroll
+        for (int r = 0; r < R; ++r) all = all && (blocked[r] || !valid[r]);
+        return __all(all) != 0;
+    };
+    auto rebuild = [&](V3 (&o)[R], float (&limit)[R]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const ShadowRay s = make_shadow_ray(st, slot[r], point, lv);
+            o[r] = s.o; limit[r] = s.limit;
+        }
+    };
 
-    unsigned long long wave_tests = 0;
+    unsigned long long wave_tests = 0;   // tests spent on still-undecided rays (wave-uniform)
     uint32_t n_full = 0;
-    bool done = shadow_wave_done<R>(s);
-    const float4* __restrict__ tri_stream = MODE == 2 ? sc.strip_light + static_cast<size_t>(light - sc.has_directional) * sc.n_tri * 2
-                                                      : (MODE == 3 ? sc.strip_any : (MODE == 1 ? sc.trif : sc.tri));
+    bool done = wave_done();
+    const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_light + static_cast<size_t>(light - sc.has_directional) * sc.n_tri
+                                                      : (MODE == 3 ? sc.strip_any : sc.tri);
     for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
         if (__syncthreads_and(done)) break;
         stage_tile<WORDS>(lds, tri_stream, first, count);
         __syncthreads();
         if (!done) {
-            wave_tests += shadow_live_tests<R>(s, count);
-            if (MODE == 2 || MODE == 3) {
-                for (uint32_t k = 0; k < count; ++k) {
-                    bool keep = false;
-                    if (MODE == 2) {
-                        const float4 s0 = lds[k * 2], s1 = lds[k * 2 + 1];
 #pragma unroll
-                        for (int r = 0; r < R; ++r) keep |= strip_keeps(line[r], s0, s1);
-                    } else {
-                        const float4 s0 = lds[k * 3], s1 = lds[k * 3 + 1], s2 = lds[k * 3 + 2];
-#pragma unroll
-                        for (int r = 0; r < R; ++r) keep |= strip_keeps_any(s.d[r], line[r], s0, s1, s2);
-                    }
-                    if (__any(keep)) {
-                        const float4* __restrict__ f = sc.trif + static_cast<size_t>(first + k) * 4;
-                        const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
-                        Pre pre[R];
-                        keep = false;
-#pragma unroll
-                        for (int r = 0; r < R; ++r) keep |= pretest_stage1(s.o[r], s.d[r], o_max[r], f0, f1, f2, pre[r]) && pretest_stage2(pre[r], f3);
-                        if (__any(keep)) {
-                            const float4* __restrict__ rec = sc.tri + static_cast<size_t>(first + k) * 4;
-                            const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3];
-#pragma unroll
-                            for (int r = 0; r < R; ++r) s.blocked[r] |= hit_triangle(s.o[r], s.d[r], e0, e1, e2, e3.x) < s.limit[r];
-                            n_full += R;
-                        }
-                    }
-                }
-            } else if (MODE == 1) {
-                for (uint32_t k = 0; k < count; ++k) {
-                    const float4 f0 = lds[k * 4], f1 = lds[k * 4 + 1], f2 = lds[k * 4 + 2];
-                    Pre pre[R];
-                    bool keep = false;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) keep |= pretest_stage1(s.o[r], s.d[r], o_max[r], f0, f1, f2, pre[r]);
-                    if (__any(keep)) {
-                        const float4 f3 = lds[k * 4 + 3];
-                        keep = false;
-#pragma unroll
-                        for (int r = 0; r < R; ++r) keep |= pretest_stage2(pre[r], f3);
-                        if (__any(keep)) {
-                            const float4* __restrict__ rec = sc.tri + static_cast<size_t>(first + k) * 4;
-                            const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3];
-#pragma unroll
-                            for (int r = 0; r < R; ++r) s.blocked[r] |= hit_triangle(s.o[r], s.d[r], e0, e1, e2, e3.x) < s.limit[r];
-                            n_full += R;
-                        }
-                    }
-                }
-            } else {
+            for (int r = 0; r < R; ++r) wave_tests += static_cast<unsigned long long>(count) * __popcll(__ballot(valid[r] && !blocked[r]));
+            if (MODE == 0) {
+                V3 o[R];
+                float limit[R];
+                rebuild(o, limit);
 #pragma unroll 2
                 for (uint32_t k = 0; k < count; ++k) {
                     const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) s.blocked[r] |= hit_triangle(s.o[r], s.d[r], t0, t1, t2, t3.x) < s.limit[r];
+                    for (int r = 0; r < R; ++r) blocked[r] |= hit_triangle(o[r], d[r], t0, t1, t2, t3.x) < limit[r];
+                }
+            } else {
+                for (uint32_t k = 0; k < count; ++k) {
+                    bool keep = keep_all;
+                    if (MODE == 2) {
+                        const float4 c = lds[k];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) keep |= cone_keeps(d[r], c);
+                    } else {
+                        const float4 s0 = lds[k * 3], s1 = lds[k * 3 + 1], s2 = lds[k * 3 + 2];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) keep |= strip_keeps_any(d[r], moment[r], s0, s1, s2);
+                    }
+                    if (__any(keep)) {
+                        V3 o[R];
+                        float limit[R], t[R];
+                        rebuild(o, limit);
+                        if (pretests_then_full<R>(sc, first + k, o, d, t)) {
+#pragma unroll
+                            for (int r = 0; r < R; ++r) blocked[r] |= t[r] < limit[r];
+                            n_full += R;
+                        }
+                    }
                 }
             }
-            done = shadow_wave_done<R>(s);
+            done = wave_done();
         }
     }
-    store_shadow_result<R>(st, s, light_bit, &st.stats[ST_SHADOW_TESTS_TRI], wave_tests);
-    if (FILTER) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (valid[r] && blocked[r]) atomicOr(&st.blocked[slot[r]], light_bit);
+    if ((threadIdx.x & 63u) == 0 && wave_tests) atomicAdd(&st.stats[ST_SHADOW_TESTS_TRI], wave_tests);
+    if (MODE != 0) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
 }
 
 template <int R>
@@ -1276,7 +1324,7 @@ uint32_t rank_tiles(const rt_render_params& p) {
 struct rt_scene {
     DevScene dev;
     std::vector<void*> allocations;
-    // strip records for rays from the eye, rebuilt when the eye moves (one render at a time per scene)
+    // cone records for rays from the eye, rebuilt when the eye moves (one render at a time per scene)
     mutable float4* eye_records = nullptr;
     mutable float eye[3] = {0, 0, 0};
     mutable bool eye_valid = false;
@@ -1353,13 +1401,13 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     hipStream_t stream = g_lib.stream;
     if (sc.n_tri && scene->eye_records) {
         if (!scene->eye_valid || std::memcmp(scene->eye, cam->eye, sizeof scene->eye) != 0) {
-            hipLaunchKernelGGL(k_prep_strip, dim3(ceil_div(sc.n_tri, BLOCK)), dim3(BLOCK), 0, stream, sc.tri, sc.n_tri,
+            hipLaunchKernelGGL(k_prep_cone, dim3(ceil_div(sc.n_tri, BLOCK)), dim3(BLOCK), 0, stream, sc.tri, sc.n_tri,
                                cam->eye[0], cam->eye[1], cam->eye[2], sc.origin_bound, 0, scene->eye_records);
             HIP_TRY(hipGetLastError());
             std::memcpy(scene->eye, cam->eye, sizeof scene->eye);
             scene->eye_valid = true;
         }
-        sc.strip_eye = scene->eye_records;
+        sc.cone_eye = scene->eye_records;
     }
     Frame f;
     std::memcpy(f.eye, cam->eye, sizeof f.eye);
@@ -1394,7 +1442,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
             timed(timer, 0, [&] {
                 if (sc.n_tri) {
                     if (!filter) hipLaunchKernelGGL((k_closest_tri<RAYS_PER_LANE, 0>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-                    else if (b == 0 && sc.strip_eye) hipLaunchKernelGGL((k_closest_tri<RAYS_PER_LANE_EYE, 2>), dim3(eye_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+                    else if (b == 0 && sc.cone_eye) hipLaunchKernelGGL((k_closest_tri<RAYS_PER_LANE_EYE, 2>), dim3(eye_blocks), dim3(BLOCK), 0, stream, sc, st, b);
                     else hipLaunchKernelGGL((k_closest_tri<RAYS_PER_LANE_EYE, 3>), dim3(eye_blocks), dim3(BLOCK), 0, stream, sc, st, b);
                 }
                 if (sc.n_sph) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
@@ -1535,11 +1583,11 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     float4 *tri, *trif, *sph, *ell, *ell_light;
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &tri))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &trif))) return fail(rc);
-    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 2, &s->eye_records))) return fail(rc);
-    float4 *strip_light, *strip_any;
-    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 2 * desc->n_point_lights, &strip_light))) return fail(rc);
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri), &s->eye_records))) return fail(rc);
+    float4 *cone_light, *strip_any;
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * desc->n_point_lights, &cone_light))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 3, &strip_any))) return fail(rc);
-    d.strip_light = strip_light;
+    d.cone_light = cone_light;
     d.strip_any = strip_any;
     {
         float b = 0.0f;
@@ -1553,8 +1601,8 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     if (d.n_tri) hipLaunchKernelGGL(k_prep_strip_any, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, tri, d.n_tri, d.origin_bound, strip_any);
     for (uint64_t l = 0; d.n_tri && l < desc->n_point_lights; ++l) {
         const float* L = desc->point_light_sources + l * 6;
-        hipLaunchKernelGGL(k_prep_strip, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, tri, d.n_tri, L[0], L[1], L[2], d.origin_bound, 1,
-                           strip_light + static_cast<size_t>(l) * d.n_tri * 2);
+        hipLaunchKernelGGL(k_prep_cone, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, tri, d.n_tri, L[0], L[1], L[2], d.origin_bound, 1,
+                           cone_light + static_cast<size_t>(l) * d.n_tri);
     }
     if (d.n_sph) hipLaunchKernelGGL(k_prep_spheres, dim3(ceil_div(d.n_sph, BLOCK)), dim3(BLOCK), 0, stream, raw_sph, d.sph_nb, sph);
     if (d.n_ell) hipLaunchKernelGGL(k_prep_ellipsoids, dim3(ceil_div(d.n_ell, BLOCK)), dim3(BLOCK), 0, stream, raw_inv, raw_fwd, d.ell_nb, ell);
