@@ -101,6 +101,7 @@ struct State {
     float *wr, *wg, *wb;                  // colour weighting
     float *cr, *cg, *cb;                  // accumulated colour
     float *px, *py, *pz, *nx, *ny, *nz;   // hit point and unit normal of the current bounce
+    unsigned long long* key;              // closest triangle of the current bounce, see pack_hit
     uint32_t* hit_id;                     // RT_ID_MAKE(kind, original index) of the current bounce
     uint32_t* blocked;                    // bit l: light l of the current group is blocked
     uint32_t* list[2];                    // compacted slots of live rays, ping-pong
@@ -659,46 +660,95 @@ DEV void load_rays(const State& st, const uint32_t* __restrict__ list_in, uint32
     }
 }
 
-// What follows a wave-uniform first pre-test that kept some lane: the two-stage pre-test on the
-// generic record, and the full test if that keeps some lane too.  Returns whether the full test ran;
-// t[r] then holds its result for ray r.
-template <int R>
-DEV bool pretests_then_full(const DevScene& sc, uint32_t k, const V3 (&o)[R], const V3 (&d)[R], float (&t)[R]) {
+// Closest triangle of a ray as one 64-bit key: distance bits in the high word, scan index in the
+// low word.  Distances the full test accepts are >= the tolerance, hence positive, so unsigned
+// order of the keys is the order of (distance, scan index): atomicMin keeps the reference's winner.
+DEV unsigned long long pack_hit(float t, uint32_t k) { return (static_cast<unsigned long long>(__float_as_uint(t)) << 32) | k; }
+constexpr unsigned long long NO_HIT_KEY = ~0ull;
+
+// Candidate (ray, triangle) pairs a wave's first pre-test kept, queued in LDS and worked off one
+// pair per lane (drain).  This keeps the scan loop free of the registers the full test needs and
+// gives the rare full tests full lanes.
+constexpr uint32_t QCAP = 192;   // entries per wave; a push adds at most 64
+struct WaveQueue {
+    uint32_t* slot;
+    uint32_t* k;
+    uint32_t* owner;
+};
+DEV void queue_push(const WaveQueue& q, uint32_t& count, bool flag, uint32_t slot, uint32_t k, uint32_t owner) {
+    const unsigned long long mask = __ballot(flag);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+    if (flag) { q.slot[pos] = slot; q.k[pos] = k; q.owner[pos] = owner; }
+    count += __popcll(mask);
+}
+
+// two-stage pre-test and, if it keeps the ray, the full test; FLT_MAX otherwise
+DEV float pretests_then_full(const DevScene& sc, uint32_t k, V3 o, V3 d, uint32_t& n_full) {
     const float4* __restrict__ f = sc.trif + static_cast<size_t>(k) * 4;
-    const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
-    bool keep = false;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        Pre pre;
-        const float o_max = fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z)));
-        keep |= pretest_stage1(o[r], d[r], o_max, f0, f1, f2, pre) && pretest_stage2(pre, f3);
-    }
-    if (!__any(keep)) return false;
+    Pre pre;
+    const float o_max = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
+    if (!(pretest_stage1(o, d, o_max, f[0], f[1], f[2], pre) && pretest_stage2(pre, f[3]))) return FLT_MAX;
     const float4* __restrict__ rec = sc.tri + static_cast<size_t>(k) * 4;
-    const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3];
-#pragma unroll
-    for (int r = 0; r < R; ++r) t[r] = hit_triangle(o[r], d[r], e0, e1, e2, e3.x);
-    return true;
+    n_full++;
+    return hit_triangle(o, d, rec[0], rec[1], rec[2], rec[3].x);
 }
 
 // MODE 0: every triangle through the full test (RT_FLAG_NO_FILTER);
 // 2: cone pre-test for rays from the eye (bounce 0); 3: strip pre-test for rays with their own origin.
-// A triangle that the first pre-test keeps for some lane of the wave goes through
-// pretests_then_full.  In modes 2 and 3 only the direction (and moment) of a ray stays in
-// registers during the scan; origins are re-read when a triangle is kept.
+// In modes 2 and 3 a lane keeps only direction (and moment) of its R rays; pairs the pre-test
+// keeps are queued and drained through pretests_then_full.  Result: st.key[slot].
 template <int R, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, uint32_t bounce) {
     constexpr int WORDS = MODE == 2 ? 1 : (MODE == 3 ? 3 : 4);
     __shared__ float4 lds[TILE_PRIMS * WORDS];
+    __shared__ uint32_t lds_queue[MODE == 0 ? 1 : (BLOCK / 64) * QCAP * 3];
     const uint32_t n_rays = st.counts[bounce];
     const uint32_t base = blockIdx.x * (BLOCK * R);
     if (base >= n_rays) return;
     const uint32_t* __restrict__ list_in = st.list[bounce & 1u];
 
+    if (MODE == 0) {
+        uint32_t slot[R];
+        bool valid[R];
+        V3 o[R], d[R];
+        float best_t[R]; uint32_t best_k[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = base + r * BLOCK + threadIdx.x;
+            valid[r] = i < n_rays;
+            slot[r] = list_in[valid[r] ? i : base];
+            o[r] = {st.ox[slot[r]], st.oy[slot[r]], st.oz[slot[r]]};
+            d[r] = {st.dx[slot[r]], st.dy[slot[r]], st.dz[slot[r]]};
+            best_t[r] = FLT_MAX; best_k[r] = 0xFFFFFFFFu;
+        }
+        for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
+            const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
+            __syncthreads();
+            stage_tile<4>(lds, sc.tri, first, count);
+            __syncthreads();
+#pragma unroll 2
+            for (uint32_t k = 0; k < count; ++k) {
+                const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float t = hit_triangle(o[r], d[r], t0, t1, t2, t3.x);
+                    if (t < best_t[r]) { best_t[r] = t; best_k[r] = first + k; }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) if (valid[r]) st.key[slot[r]] = best_k[r] == 0xFFFFFFFFu ? NO_HIT_KEY : pack_hit(best_t[r], best_k[r]);
+        return;
+    }
+
+    const uint32_t wave = threadIdx.x >> 6;
+    const WaveQueue q{lds_queue + wave * QCAP * 3, lds_queue + wave * QCAP * 3 + QCAP, lds_queue + wave * QCAP * 3 + 2 * QCAP};
+    uint32_t q_count = 0, n_full = 0;
+
     uint32_t slot[R];
     bool valid[R];
     V3 d[R], moment[R];
-    float best_t[R]; uint32_t best_k[R];
     bool unsafe = false;    // an origin outside the bound the strip records were built for: keep everything
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -709,63 +759,50 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
         d[r] = {st.dx[slot[r]], st.dy[slot[r]], st.dz[slot[r]]};
         moment[r] = scross(o, d[r]);
         unsafe |= !(fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))) <= sc.origin_bound);
-        best_t[r] = FLT_MAX; best_k[r] = 0xFFFFFFFFu;
+        if (valid[r]) st.key[slot[r]] = NO_HIT_KEY;   // completed by the barrier below, long before any atomicMin on it
     }
     const bool keep_all = MODE == 3 && __any(unsafe);
-    uint32_t n_full = 0;
 
-    auto origins = [&](V3 (&o)[R]) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) o[r] = {st.ox[slot[r]], st.oy[slot[r]], st.oz[slot[r]]};
+    auto drain = [&]() {
+        for (uint32_t i = threadIdx.x & 63u; i < q_count; i += 64) {
+            const uint32_t s = q.slot[i], k = q.k[i];
+            const V3 o{st.ox[s], st.oy[s], st.oz[s]};
+            const V3 dd{st.dx[s], st.dy[s], st.dz[s]};
+            const float t = pretests_then_full(sc, k, o, dd, n_full);
+            if (t < FLT_MAX) atomicMin(&st.key[s], pack_hit(t, k));
+        }
+        q_count = 0;
     };
-    const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_eye : (MODE == 3 ? sc.strip_any : sc.tri);
+
+    const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_eye : sc.strip_any;
     for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
         __syncthreads();
         stage_tile<WORDS>(lds, tri_stream, first, count);
         __syncthreads();
-        if (MODE == 0) {
-            V3 o[R];
-            origins(o);
-#pragma unroll 2
-            for (uint32_t k = 0; k < count; ++k) {
-                const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
+        for (uint32_t k = 0; k < count; ++k) {
+            bool keep[R];
+            bool any = keep_all;
+            if (MODE == 2) {
+                const float4 c = lds[k];
+#pragma unroll
+                for (int r = 0; r < R; ++r) { keep[r] = cone_keeps(d[r], c); any |= keep[r]; }
+            } else {
+                const float4 s0 = lds[k * 3], s1 = lds[k * 3 + 1], s2 = lds[k * 3 + 2];
+#pragma unroll
+                for (int r = 0; r < R; ++r) { keep[r] = strip_keeps_any(d[r], moment[r], s0, s1, s2); any |= keep[r]; }
+            }
+            if (__any(any)) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const float t = hit_triangle(o[r], d[r], t0, t1, t2, t3.x);
-                    if (t < best_t[r]) { best_t[r] = t; best_k[r] = first + k; }
-                }
-            }
-        } else {
-            for (uint32_t k = 0; k < count; ++k) {
-                bool keep = keep_all;
-                if (MODE == 2) {
-                    const float4 c = lds[k];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) keep |= cone_keeps(d[r], c);
-                } else {
-                    const float4 s0 = lds[k * 3], s1 = lds[k * 3 + 1], s2 = lds[k * 3 + 2];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) keep |= strip_keeps_any(d[r], moment[r], s0, s1, s2);
-                }
-                if (__any(keep)) {
-                    V3 o[R];
-                    float t[R];
-                    origins(o);
-                    if (pretests_then_full<R>(sc, first + k, o, d, t)) {
-#pragma unroll
-                        for (int r = 0; r < R; ++r) if (t[r] < best_t[r]) { best_t[r] = t[r]; best_k[r] = first + k; }
-                        n_full += R;
-                    }
+                    if (q_count + 64 > QCAP) drain();
+                    queue_push(q, q_count, (keep[r] || keep_all) && valid[r], slot[r], first + k, 0u);
                 }
             }
         }
     }
-    float* out_t = closest_t_slot(st, 0);
-    uint32_t* out_k = closest_k_slot(st, 0);
-#pragma unroll
-    for (int r = 0; r < R; ++r) if (valid[r]) { out_t[slot[r]] = best_t[r]; out_k[slot[r]] = best_k[r]; }
-    if (MODE != 0) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
+    drain();
+    block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
 }
 
 template <int R>
@@ -849,7 +886,11 @@ __global__ void __launch_bounds__(BLOCK) k_hit(DevScene sc, State st, uint32_t b
 
     float t_kind[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
     uint32_t k_kind[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    if (sc.n_tri) { t_kind[0] = closest_t_slot(st, 0)[s]; k_kind[0] = closest_k_slot(st, 0)[s]; }
+    if (sc.n_tri) {
+        const unsigned long long key = st.key[s];
+        k_kind[0] = static_cast<uint32_t>(key & 0xFFFFFFFFull);
+        if (k_kind[0] != 0xFFFFFFFFu) t_kind[0] = __uint_as_float(static_cast<uint32_t>(key >> 32));
+    }
     if (sc.n_sph) { t_kind[1] = closest_t_slot(st, 1)[s]; k_kind[1] = closest_k_slot(st, 1)[s]; }
     if (sc.n_ell) { t_kind[2] = closest_t_slot(st, 2)[s]; k_kind[2] = closest_k_slot(st, 2)[s]; }
     const float tri_t = t_kind[0], sph_t = t_kind[1], ell_t = t_kind[2];
@@ -993,11 +1034,14 @@ DEV ShadowRay make_shadow_ray(const State& st, uint32_t slot, bool point, V3 lv)
 
 // MODE 0: full test only; 2: cone pre-test (point lights only: lights first_light.. are point
 // lights, their cone records start at sc.cone_light); 3: strip pre-test for rays with their own
-// origin (any light).  As in k_closest_tri only the direction (and moment) stays in registers.
+// origin (any light).  Queue and drain as in k_closest_tri; a drained pair that blocks sets the
+// owner's bit in LDS, which the owner picks up after the drain.
 template <int R, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
     constexpr int WORDS = MODE == 2 ? 1 : (MODE == 3 ? 3 : 4);
     __shared__ float4 lds[TILE_PRIMS * WORDS];
+    __shared__ uint32_t lds_queue[MODE == 0 ? 1 : (BLOCK / 64) * QCAP * 3];
+    __shared__ uint32_t lds_blocked[BLOCK];   // bit r: ray r of that thread is blocked (set by drains)
     const uint32_t n_rays = st.counts[bounce + 1];
     const uint32_t base = blockIdx.x * (BLOCK * R);
     if (base >= n_rays) return;
@@ -1023,6 +1067,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
         unsafe |= !(fmaxf(fabsf(s.o.x), fmaxf(fabsf(s.o.y), fabsf(s.o.z))) <= sc.origin_bound);
         blocked[r] = (st.blocked[slot[r]] & light_bit) != 0u;
     }
+    lds_blocked[threadIdx.x] = 0u;
     const bool keep_all = MODE != 0 && __any(unsafe);
     auto wave_done = [&]() {
         bool all = true;
@@ -1030,16 +1075,24 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
         for (int r = 0; r < R; ++r) all = all && (blocked[r] || !valid[r]);
         return __all(all) != 0;
     };
-    auto rebuild = [&](V3 (&o)[R], float (&limit)[R]) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const ShadowRay s = make_shadow_ray(st, slot[r], point, lv);
-            o[r] = s.o; limit[r] = s.limit;
+
+    const uint32_t wave = threadIdx.x >> 6;
+    const WaveQueue q{lds_queue + wave * QCAP * 3, lds_queue + wave * QCAP * 3 + QCAP, lds_queue + wave * QCAP * 3 + 2 * QCAP};
+    uint32_t q_count = 0, n_full = 0;
+    auto drain = [&]() {
+        for (uint32_t i = threadIdx.x & 63u; i < q_count; i += 64) {
+            const uint32_t k = q.k[i], owner = q.owner[i];
+            const ShadowRay s = make_shadow_ray(st, q.slot[i], point, lv);
+            const float t = pretests_then_full(sc, k, s.o, s.d, n_full);
+            if (t < s.limit) atomicOr(&lds_blocked[owner >> 8], 1u << (owner & 255u));
         }
+        q_count = 0;
+        const uint32_t mine = lds_blocked[threadIdx.x];
+#pragma unroll
+        for (int r = 0; r < R; ++r) blocked[r] |= ((mine >> r) & 1u) != 0u;
     };
 
     unsigned long long wave_tests = 0;   // tests spent on still-undecided rays (wave-uniform)
-    uint32_t n_full = 0;
     bool done = wave_done();
     const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_light + static_cast<size_t>(light - sc.has_directional) * sc.n_tri
                                                       : (MODE == 3 ? sc.strip_any : sc.tri);
@@ -1054,7 +1107,11 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
             if (MODE == 0) {
                 V3 o[R];
                 float limit[R];
-                rebuild(o, limit);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const ShadowRay s = make_shadow_ray(st, slot[r], point, lv);
+                    o[r] = s.o; limit[r] = s.limit;
+                }
 #pragma unroll 2
                 for (uint32_t k = 0; k < count; ++k) {
                     const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
@@ -1063,27 +1120,26 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
                 }
             } else {
                 for (uint32_t k = 0; k < count; ++k) {
-                    bool keep = keep_all;
+                    bool keep[R];
+                    bool any = keep_all;
                     if (MODE == 2) {
                         const float4 c = lds[k];
 #pragma unroll
-                        for (int r = 0; r < R; ++r) keep |= cone_keeps(d[r], c);
+                        for (int r = 0; r < R; ++r) { keep[r] = cone_keeps(d[r], c); any |= keep[r]; }
                     } else {
                         const float4 s0 = lds[k * 3], s1 = lds[k * 3 + 1], s2 = lds[k * 3 + 2];
 #pragma unroll
-                        for (int r = 0; r < R; ++r) keep |= strip_keeps_any(d[r], moment[r], s0, s1, s2);
+                        for (int r = 0; r < R; ++r) { keep[r] = strip_keeps_any(d[r], moment[r], s0, s1, s2); any |= keep[r]; }
                     }
-                    if (__any(keep)) {
-                        V3 o[R];
-                        float limit[R], t[R];
-                        rebuild(o, limit);
-                        if (pretests_then_full<R>(sc, first + k, o, d, t)) {
+                    if (__any(any)) {
 #pragma unroll
-                            for (int r = 0; r < R; ++r) blocked[r] |= t[r] < limit[r];
-                            n_full += R;
+                        for (int r = 0; r < R; ++r) {
+                            if (q_count + 64 > QCAP) drain();
+                            queue_push(q, q_count, (keep[r] || keep_all) && valid[r] && !blocked[r], slot[r], first + k, (threadIdx.x << 8) | static_cast<uint32_t>(r));
                         }
                     }
                 }
+                drain();
             }
             done = wave_done();
         }
@@ -1297,7 +1353,7 @@ constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;
 // The eye-ray scan executes so few instructions per test that, with 2 rays per lane, the LDS
 // broadcast reads of the records (10 LDS cycles per triangle per wave) become the limit.
 constexpr int RAYS_PER_LANE_EYE = RT_RAYS_PER_LANE_EYE;
-constexpr uint32_t DEFAULT_CHUNK_TILES = 8192;   // 33.5 M samples, 3.1 GB of ray state
+constexpr uint32_t DEFAULT_CHUNK_TILES = 8192;   // 33.5 M samples, 3.4 GB of ray state
 constexpr uint32_t MAX_BOUNCES = 62;
 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
@@ -1335,8 +1391,8 @@ namespace {
 int ensure_state(size_t samples) {
     if (g_lib.state_samples >= samples) return 0;
     if (g_lib.state_mem) { HIP_TRY(hipFree(g_lib.state_mem)); g_lib.state_mem = nullptr; g_lib.state_samples = 0; }
-    // 18 float arrays + hit_id + blocked + 2 lists + primary ids = 23 words per sample
-    HIP_TRY(hipMalloc(&g_lib.state_mem, samples * 23 * sizeof(float)));
+    // 18 float arrays + hit_id + blocked + 2 lists + primary ids + 64-bit keys = 25 words per sample
+    HIP_TRY(hipMalloc(&g_lib.state_mem, samples * 25 * sizeof(float)));
     g_lib.state_samples = samples;
     return 0;
 }
@@ -1351,6 +1407,7 @@ State make_state(size_t samples, bool want_ids) {
     uint32_t* u = reinterpret_cast<uint32_t*>(f + samples * k);
     st.hit_id = u; st.blocked = u + samples; st.list[0] = u + 2 * samples; st.list[1] = u + 3 * samples;
     st.primary_id = want_ids ? u + 4 * samples : nullptr;
+    st.key = reinterpret_cast<unsigned long long*>(u + 5 * samples);   // 8-byte aligned: samples is a multiple of 4096
     st.counts = g_lib.counts;
     st.stats = g_lib.stats;
     return st;
