@@ -164,6 +164,12 @@ DEV V3 smat_transpose_dir(float4 r0, float4 r1, float4 r2, V3 v) {
             fma_(r2.z, v.z, fma_(r0.z, v.x, r1.z * v.y))};
 }
 
+// Closest triangle of a ray as one 64-bit key: distance bits in the high word, scan index in the
+// low word.  Distances the full test accepts are >= the tolerance, hence positive, so unsigned
+// order of the keys is the order of (distance, scan index): atomicMin keeps the reference's winner.
+DEV unsigned long long pack_hit(float t, uint32_t k) { return (static_cast<unsigned long long>(__float_as_uint(t)) << 32) | k; }
+constexpr unsigned long long NO_HIT_KEY = ~0ull;
+
 // fp_pow and its helpers (maths.cpp:9-139)
 DEV int exponent_127(float x) { return static_cast<int>((__float_as_uint(x) >> 23) & 0xFFu); }
 DEV float fp_log2(float x) {
@@ -618,6 +624,7 @@ __global__ void __launch_bounds__(BLOCK) k_primary(Frame f, DevScene sc, State s
         st.dx[s] = d.x; st.dy[s] = d.y; st.dz[s] = d.z;
         st.wr[s] = 1.0f; st.wg[s] = 1.0f; st.wb[s] = 1.0f;
     }
+    if (live) st.key[s] = NO_HIT_KEY;
     if (st.primary_id) st.primary_id[s] = live ? RT_ID_MISS : RT_ID_CULLED;
     const uint32_t pos = block_append(live, &st.counts[0], lds_scan);
     if (live) st.list[0][pos] = s;
@@ -660,11 +667,30 @@ DEV void load_rays(const State& st, const uint32_t* __restrict__ list_in, uint32
     }
 }
 
-// Closest triangle of a ray as one 64-bit key: distance bits in the high word, scan index in the
-// low word.  Distances the full test accepts are >= the tolerance, hence positive, so unsigned
-// order of the keys is the order of (distance, scan index): atomicMin keeps the reference's winner.
-DEV unsigned long long pack_hit(float t, uint32_t k) { return (static_cast<unsigned long long>(__float_as_uint(t)) << 32) | k; }
-constexpr unsigned long long NO_HIT_KEY = ~0ull;
+// Work split of a pre-test scan launch.  A workgroup owns BLOCK*R rays and normally walks the
+// whole triangle list.  When a launch has few rays (deep bounces) that would leave most of the
+// chip idle for the time one wave needs to walk the list, so the list is cut into S segments of
+// whole tiles and (ray block, segment) pairs are spread over the grid; results combine through
+// atomicMin / atomicOr.  S is derived from the ray count alone, so every workgroup agrees on it.
+constexpr uint32_t SEG_TARGET = 4096;   // workgroups a small launch is spread over
+struct ScanSplit { uint32_t ray_base, first_prim, end_prim; bool active; };
+DEV ScanSplit scan_split(uint32_t n_rays, uint32_t rays_per_block, uint32_t n_prims) {
+    ScanSplit sp{0, 0, 0, false};
+    const uint32_t n_blocks = (n_rays + rays_per_block - 1) / rays_per_block;
+    if (n_blocks == 0) return sp;
+    const uint32_t n_tiles = (n_prims + TILE_PRIMS - 1) / TILE_PRIMS;
+    uint32_t segments = SEG_TARGET / n_blocks;
+    segments = segments < 1 ? 1 : (segments > n_tiles ? n_tiles : segments);
+    if (segments == 0 || blockIdx.x >= n_blocks * segments) return sp;
+    const uint32_t tiles_per_segment = (n_tiles + segments - 1) / segments;
+    const uint32_t seg = blockIdx.x % segments;
+    sp.ray_base = (blockIdx.x / segments) * rays_per_block;
+    sp.first_prim = seg * tiles_per_segment * TILE_PRIMS;
+    sp.end_prim = min(n_prims, (seg + 1) * tiles_per_segment * TILE_PRIMS);
+    sp.active = sp.first_prim < sp.end_prim;
+    return sp;
+}
+
 
 // Candidate (ray, triangle) pairs a wave's first pre-test kept, queued in LDS and worked off one
 // pair per lane (drain).  This keeps the scan loop free of the registers the full test needs and
@@ -704,9 +730,15 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
     __shared__ float4 lds[TILE_PRIMS * WORDS];
     __shared__ uint32_t lds_queue[MODE == 0 ? 1 : (BLOCK / 64) * QCAP * 3];
     const uint32_t n_rays = st.counts[bounce];
-    const uint32_t base = blockIdx.x * (BLOCK * R);
-    if (base >= n_rays) return;
     const uint32_t* __restrict__ list_in = st.list[bounce & 1u];
+    ScanSplit split;
+    if (MODE == 0) {
+        split = ScanSplit{blockIdx.x * (BLOCK * R), 0u, sc.n_tri, blockIdx.x * (BLOCK * R) < n_rays};
+    } else {
+        split = scan_split(n_rays, BLOCK * R, sc.n_tri);
+    }
+    if (!split.active) return;
+    const uint32_t base = split.ray_base;
 
     if (MODE == 0) {
         uint32_t slot[R];
@@ -759,7 +791,6 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
         d[r] = {st.dx[slot[r]], st.dy[slot[r]], st.dz[slot[r]]};
         moment[r] = scross(o, d[r]);
         unsafe |= !(fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))) <= sc.origin_bound);
-        if (valid[r]) st.key[slot[r]] = NO_HIT_KEY;   // completed by the barrier below, long before any atomicMin on it
     }
     const bool keep_all = MODE == 3 && __any(unsafe);
 
@@ -775,8 +806,8 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
     };
 
     const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_eye : sc.strip_any;
-    for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
-        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
+    for (uint32_t first = split.first_prim; first < split.end_prim; first += TILE_PRIMS) {
+        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), split.end_prim - first);
         __syncthreads();
         stage_tile<WORDS>(lds, tri_stream, first, count);
         __syncthreads();
@@ -946,6 +977,7 @@ __global__ void __launch_bounds__(BLOCK) k_hit(DevScene sc, State st, uint32_t b
         const uint32_t id = RT_ID_MAKE(static_cast<uint32_t>(kind), index);
         st.hit_id[s] = id;
         st.blocked[s] = 0u;
+        st.key[s] = NO_HIT_KEY;      // for the next bounce's triangle scan
         if (bounce == 0 && st.primary_id) st.primary_id[s] = id;
     }
     const uint32_t pos = block_append(hit, &st.counts[bounce + 1], lds_scan);
@@ -1043,8 +1075,14 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
     __shared__ uint32_t lds_queue[MODE == 0 ? 1 : (BLOCK / 64) * QCAP * 3];
     __shared__ uint32_t lds_blocked[BLOCK];   // bit r: ray r of that thread is blocked (set by drains)
     const uint32_t n_rays = st.counts[bounce + 1];
-    const uint32_t base = blockIdx.x * (BLOCK * R);
-    if (base >= n_rays) return;
+    ScanSplit split;
+    if (MODE == 0) {
+        split = ScanSplit{blockIdx.x * (BLOCK * R), 0u, sc.n_tri, blockIdx.x * (BLOCK * R) < n_rays};
+    } else {
+        split = scan_split(n_rays, BLOCK * R, sc.n_tri);
+    }
+    if (!split.active) return;
+    const uint32_t base = split.ray_base;
     const uint32_t* __restrict__ list_in = st.list[(bounce + 1) & 1u];
     const uint32_t light = first_light + blockIdx.y;
     const float* __restrict__ L = sc.lights + light * 8;
@@ -1096,8 +1134,8 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
     bool done = wave_done();
     const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_light + static_cast<size_t>(light - sc.has_directional) * sc.n_tri
                                                       : (MODE == 3 ? sc.strip_any : sc.tri);
-    for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
-        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
+    for (uint32_t first = split.first_prim; first < split.end_prim; first += TILE_PRIMS) {
+        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), split.end_prim - first);
         if (__syncthreads_and(done)) break;
         stage_tile<WORDS>(lds, tri_stream, first, count);
         __syncthreads();
@@ -1346,13 +1384,22 @@ Library g_lib;
 #ifndef RT_RAYS_PER_LANE
 #define RT_RAYS_PER_LANE 2
 #endif
-#ifndef RT_RAYS_PER_LANE_EYE
-#define RT_RAYS_PER_LANE_EYE 4
+#ifndef RT_R_CONE
+#define RT_R_CONE 4
 #endif
-constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;
-// The eye-ray scan executes so few instructions per test that, with 2 rays per lane, the LDS
-// broadcast reads of the records (10 LDS cycles per triangle per wave) become the limit.
-constexpr int RAYS_PER_LANE_EYE = RT_RAYS_PER_LANE_EYE;
+#ifndef RT_R_STRIP
+#define RT_R_STRIP 4
+#endif
+#ifndef RT_R_SHADOW_CONE
+#define RT_R_SHADOW_CONE 4
+#endif
+#ifndef RT_R_SHADOW_STRIP
+#define RT_R_SHADOW_STRIP 4
+#endif
+constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;   // full-test, sphere and ellipsoid scans
+// The pre-test scans execute so few instructions per test that the LDS broadcast reads of the
+// records (4 LDS cycles per float4 per wave) only stay hidden with several rays per lane.
+constexpr int R_CONE = RT_R_CONE, R_STRIP = RT_R_STRIP, R_SHADOW_CONE = RT_R_SHADOW_CONE, R_SHADOW_STRIP = RT_R_SHADOW_STRIP;
 constexpr uint32_t DEFAULT_CHUNK_TILES = 8192;   // 33.5 M samples, 3.4 GB of ray state
 constexpr uint32_t MAX_BOUNCES = 62;
 
@@ -1493,14 +1540,17 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         HIP_TRY(hipMemsetAsync(g_lib.counts, 0, 64 * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(k_primary, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, f, sc, st, first);
         const uint32_t scan_blocks = ceil_div(n_samples, BLOCK * RAYS_PER_LANE);
-        const uint32_t eye_blocks = ceil_div(n_samples, BLOCK * RAYS_PER_LANE_EYE);
+        auto blocks_for = [&](int rays_per_lane) {   // worst-case ray blocks, and room for the split of a small launch
+            const uint32_t blocks = ceil_div(n_samples, static_cast<uint32_t>(BLOCK * rays_per_lane));
+            return blocks > SEG_TARGET ? blocks : SEG_TARGET;
+        };
         const uint32_t ray_blocks = n_samples / BLOCK;
         for (uint32_t b = 0; b < depth; ++b) {
             timed(timer, 0, [&] {
                 if (sc.n_tri) {
                     if (!filter) hipLaunchKernelGGL((k_closest_tri<RAYS_PER_LANE, 0>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-                    else if (b == 0 && sc.cone_eye) hipLaunchKernelGGL((k_closest_tri<RAYS_PER_LANE_EYE, 2>), dim3(eye_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-                    else hipLaunchKernelGGL((k_closest_tri<RAYS_PER_LANE_EYE, 3>), dim3(eye_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+                    else if (b == 0 && sc.cone_eye) hipLaunchKernelGGL((k_closest_tri<R_CONE, 2>), dim3(blocks_for(R_CONE)), dim3(BLOCK), 0, stream, sc, st, b);
+                    else hipLaunchKernelGGL((k_closest_tri<R_STRIP, 3>), dim3(blocks_for(R_STRIP)), dim3(BLOCK), 0, stream, sc, st, b);
                 }
                 if (sc.n_sph) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
                 if (sc.n_ell) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
@@ -1518,8 +1568,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                         if (sc.n_tri) {
                             if (!filter) hipLaunchKernelGGL((k_shadow_tri<RAYS_PER_LANE, 0>), dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
                             else {
-                                if (n_dir) hipLaunchKernelGGL((k_shadow_tri<RAYS_PER_LANE_EYE, 3>), dim3(eye_blocks, 1), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
-                                if (n_pt) hipLaunchKernelGGL((k_shadow_tri<RAYS_PER_LANE_EYE, 2>), dim3(eye_blocks, n_pt), dim3(BLOCK), 0, stream, sc, st, b, l0 + n_dir, l0);
+                                if (n_dir) hipLaunchKernelGGL((k_shadow_tri<R_SHADOW_STRIP, 3>), dim3(blocks_for(R_SHADOW_STRIP), 1), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
+                                if (n_pt) hipLaunchKernelGGL((k_shadow_tri<R_SHADOW_CONE, 2>), dim3(blocks_for(R_SHADOW_CONE), n_pt), dim3(BLOCK), 0, stream, sc, st, b, l0 + n_dir, l0);
                             }
                         }
                         if (sc.n_sph) hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
