@@ -68,7 +68,7 @@ struct DevScene {
     const float4* trif;  // pre-test records, 4 x float4 per triangle, see pretest_stage1
     const float4* cone_eye;     // cone records (1 x float4 per triangle) for rays from the camera eye, see cone_keeps
     const float4* cone_light;   // [point light][triangle] cone records for shadow rays toward that light
-    const float4* strip_any;    // strip records (3 x float4 per triangle) for rays with their own origin, see strip_keeps_any
+    const float4* sphere_any;   // bounding-sphere records (1 x float4 per triangle) for rays with their own origin, see sphere_keeps
     const float4* sph;   // (centre, radius)
     const float4* ell;   // 6 x float4: rows of the inverse transform, rows of the transform
     const float4* ell_light;  // [point light][ellipsoid]: inverse transform applied to the light position
@@ -271,26 +271,19 @@ DEV bool pretest_stage2(const Pre& s, float4 f3) {
 // cosine lowered by the rounding of d.axis; cos = -2 keeps every ray.  NaN keeps the ray.
 DEV bool cone_keeps(V3 d, float4 c) { return !(vdot(d, xyz(c)) < c.w); }
 
-// Strip pre-test for a ray with its own origin o.  With num = (a - o).n, c1 = w1.(a - o),
-// alpha = t (w1.d) - c1 and t = num / (d.n):
-//     (alpha - 0.5) (d.n) = V.d,   V = num w1 - (c1 + 0.5) n,
-// so "alpha is outside [-2m, 1 + 2m]" becomes |V.d| > kappa |d.n| with kappa = 0.5 + 2m, and no
-// reciprocal is needed.  In the ray's Pluecker coordinates (d, m = o x d), with U = w1 x n,
-//     V.d = d.(a x U - 0.5 n) + m.U
-// (expand (a - o) x (w1 x n)), a six-term dot product with per-triangle constants.
-// Record: (n, Ws.x) (Ws.y, Ws.z, Us.x, Us.y) (Us.z, 0, 0, 0), Ws = (a x U - 0.5 n)/kappa, Us = U/kappa
-// (k_prep_strip_any, in double).  kappa also covers the rounding of m and of this form, including
-// the terms that do not scale with |d.n| (bounded through the full test's own |d.n| >= tolerance);
-// DESIGN.md "Strip pre-test".  Ws = Us = 0 keeps every ray.
-DEV bool strip_keeps_any(V3 d, V3 m, float4 s0, float4 s1, float4 s2) {
-    const float dn = vdot(d, xyz(s0));
-    float x = d.x * s0.w;
-    x = fma_(d.y, s1.x, x);
-    x = fma_(d.z, s1.y, x);
-    x = fma_(m.x, s1.z, x);
-    x = fma_(m.y, s1.w, x);
-    x = fma_(m.z, s2.x, x);
-    return !(__builtin_fabsf(x) > __builtin_fabsf(dn));
+// Sphere pre-test for a ray with its own origin o, in its Pluecker coordinates (d, m = o x d)
+// with d of unit length: the distance of a point c from the ray's line is |c x d - m|.  If that
+// exceeds the radius of a sphere around c that contains the triangle (inflated by the margin m of
+// the two-stage pre-test) the ray cannot hit.  Six multiply-adds for c x d - m, three for the
+// squared length, one compare; the record (k_prep_sphere, in double) is (c, r^2) with r enlarged
+// by the rounding of m, of this expression and of the normalised direction.  r^2 = inf keeps every
+// ray; NaN keeps the ray.
+DEV bool sphere_keeps(V3 d, V3 m, float4 c) {
+    const float vx = fma_(c.y, d.z, fma_(-c.z, d.y, -m.x));
+    const float vy = fma_(c.z, d.x, fma_(-c.x, d.z, -m.y));
+    const float vz = fma_(c.x, d.y, fma_(-c.y, d.x, -m.z));
+    const float q = fma_(vz, vz, fma_(vy, vy, vx * vx));
+    return !(q > c.w);
 }
 
 // ray_tracing.cpp:169-206; the far root is replaced by the near one at :202 and that is kept
@@ -498,51 +491,42 @@ __global__ void __launch_bounds__(BLOCK) k_prep_cone(const float4* __restrict__ 
     out[k] = rec;
 }
 
-// Strip records for rays with their own origin (strip_keeps_any); origins lie within origin_bound of 0.
-__global__ void __launch_bounds__(BLOCK) k_prep_strip_any(const float4* __restrict__ tri, uint32_t n_tri, float origin_bound, float4* __restrict__ out) {
+// Bounding-sphere records (sphere_keeps) for rays whose origins lie within origin_bound of 0.
+// As in k_prep_cone: when the full test accepts, its hit point lies within delta of the triangle
+// scaled by (1 + 3m) about its centroid c.
+__global__ void __launch_bounds__(BLOCK) k_prep_sphere(const float4* __restrict__ tri, uint32_t n_tri, float origin_bound, float4* __restrict__ out) {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= n_tri) return;
     const float4 t0 = tri[static_cast<size_t>(k) * 4], t1 = tri[static_cast<size_t>(k) * 4 + 1], t2 = tri[static_cast<size_t>(k) * 4 + 2], t3 = tri[static_cast<size_t>(k) * 4 + 3];
     const double a[3] = {t0.x, t0.y, t0.z}, n[3] = {t0.w, t1.w, t2.w}, ab[3] = {t1.x, t1.y, t1.z}, ac[3] = {t2.x, t2.y, t2.z};
     const double nn = static_cast<double>(t3.x);
-    auto cross = [](const double* l, const double* r, double* o) { o[0] = l[1] * r[2] - l[2] * r[1]; o[1] = l[2] * r[0] - l[0] * r[2]; o[2] = l[0] * r[1] - l[1] * r[0]; };
     auto max3 = [](const double* v) { return fmax(fabs(v[0]), fmax(fabs(v[1]), fabs(v[2]))); };
-    auto one3 = [](const double* v) { return fabs(v[0]) + fabs(v[1]) + fabs(v[2]); };
     auto len3 = [](const double* v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
-    double w1[3], U[3], W[3];
-    cross(n, ab, w1);
-    for (int i = 0; i < 3; ++i) w1[i] /= nn;
-    cross(w1, n, U);
-    cross(a, U, W);
-    for (int i = 0; i < 3; ++i) W[i] -= 0.5 * n[i];
-    const double eps = 5.9604644775390625e-8;   // 2^-24
-    const double B = origin_bound;
-    const double n_one = one3(n);
-    const double Q = max3(n) * fmax(max3(ab), max3(ac)) / nn;
-    const double edges = len3(ab) + len3(ac);
-    const double reach = max3(a) + B;                                  // |a - o|_inf for any origin
-    const double T = 2.0 * (1.7320508075688772 * reach + edges);       // distance from the origin to any accepted hit, with slack
-    const double tol_eff = 0.999e-4;
-    const double S = B + T + max3(a);
-    double bracket = 48.0 * eps * Q * S + 6.0 * eps * Q * T + eps;     // full test against real arithmetic, reciprocal-free t
-    bracket += eps * (7.0 * one3(W) + 18.0 * B * one3(U)               // rounding of the six-term product and of m = o x d
-                      + 24.0 * Q * n_one * reach                        // rounding of (a - o).n in the full test
-                      + 3.0 * (6.0 * Q * reach + 0.5) * n_one) / tol_eff;   // rounding of d.n
-    const double kappa = 0.5 + 2.0 * bracket;
-    float ws[3] = {0.0f, 0.0f, 0.0f}, us[3] = {0.0f, 0.0f, 0.0f};
-    if (nn > 0.0 && kappa < 1.0e30) {
-        bool ok = true;
-        for (int i = 0; i < 3; ++i) {
-            ws[i] = static_cast<float>(W[i] / kappa);
-            us[i] = static_cast<float>(U[i] / kappa);
-            ok = ok && fabsf(ws[i]) < 1.0e30f && fabsf(us[i]) < 1.0e30f;
+    float4 rec = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());   // keeps every ray
+    if (nn > 0.0) {
+        const double eps = 5.9604644775390625e-8;   // 2^-24
+        const double B = origin_bound;
+        const double Q = max3(n) * fmax(max3(ab), max3(ac)) / nn;
+        const double edges = len3(ab) + len3(ac);
+        const double T = 2.0 * (1.7320508075688772 * (max3(a) + B) + edges);   // origin to any accepted hit, with slack
+        const double m = 2.0 * (48.0 * eps * Q * (B + T + max3(a)) + eps);
+        double c[3], r = 0.0;
+        for (int i = 0; i < 3; ++i) c[i] = a[i] + (ab[i] + ac[i]) / 3.0;
+        const double v[3][3] = {{a[0], a[1], a[2]}, {a[0] + ab[0], a[1] + ab[1], a[2] + ab[2]}, {a[0] + ac[0], a[1] + ac[1], a[2] + ac[2]}};
+        for (int j = 0; j < 3; ++j) {
+            const double e[3] = {v[j][0] - c[0], v[j][1] - c[1], v[j][2] - c[2]};
+            r = fmax(r, len3(e));
         }
-        if (!ok) for (int i = 0; i < 3; ++i) ws[i] = us[i] = 0.0f;
+        r *= 1.0 + 3.0 * m;
+        // hit point off the plane, direction normalised in binary32, centre rounded to binary32; then the
+        // rounding of m = o x d and of c x d - m
+        const double r_tot = (r + 2.0 * (13.0 * eps * T + 3.0 * eps * T + 2.0 * eps * max3(c))) * (1.0 + 6.0 * eps)
+                             + 2.0 * 13.0 * eps * (max3(c) + B);
+        const double r2 = r_tot * r_tot * (1.0 + 1.0e-6);
+        if (r2 < 1.0e30 && m < 1.0e6)
+            rec = make_float4(static_cast<float>(c[0]), static_cast<float>(c[1]), static_cast<float>(c[2]), nextafterf(static_cast<float>(r2), __builtin_inff()));
     }
-    float4* q = out + static_cast<size_t>(k) * 3;
-    q[0] = make_float4(static_cast<float>(n[0]), static_cast<float>(n[1]), static_cast<float>(n[2]), ws[0]);
-    q[1] = make_float4(ws[1], ws[2], us[0], us[1]);
-    q[2] = make_float4(us[2], 0.0f, 0.0f, 0.0f);
+    out[k] = rec;
 }
 
 __global__ void __launch_bounds__(BLOCK) k_prep_spheres(const float* __restrict__ sph8, uint32_t nb, float4* __restrict__ out) {
@@ -721,12 +705,12 @@ DEV float pretests_then_full(const DevScene& sc, uint32_t k, V3 o, V3 d, uint32_
 }
 
 // MODE 0: every triangle through the full test (RT_FLAG_NO_FILTER);
-// 2: cone pre-test for rays from the eye (bounce 0); 3: strip pre-test for rays with their own origin.
+// 2: cone pre-test for rays from the eye (bounce 0); 3: bounding-sphere pre-test for rays with their own origin.
 // In modes 2 and 3 a lane keeps only direction (and moment) of its R rays; pairs the pre-test
 // keeps are queued and drained through pretests_then_full.  Result: st.key[slot].
 template <int R, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, uint32_t bounce) {
-    constexpr int WORDS = MODE == 2 ? 1 : (MODE == 3 ? 3 : 4);
+    constexpr int WORDS = MODE == 0 ? 4 : 1;
     __shared__ float4 lds[TILE_PRIMS * WORDS];
     __shared__ uint32_t lds_queue[MODE == 0 ? 1 : (BLOCK / 64) * QCAP * 3];
     const uint32_t n_rays = st.counts[bounce];
@@ -781,7 +765,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
     uint32_t slot[R];
     bool valid[R];
     V3 d[R], moment[R];
-    bool unsafe = false;    // an origin outside the bound the strip records were built for: keep everything
+    bool unsafe = false;    // an origin outside the bound the sphere records were built for: keep everything
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t i = base + r * BLOCK + threadIdx.x;
@@ -789,6 +773,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
         slot[r] = list_in[valid[r] ? i : base];
         const V3 o{st.ox[slot[r]], st.oy[slot[r]], st.oz[slot[r]]};
         d[r] = {st.dx[slot[r]], st.dy[slot[r]], st.dz[slot[r]]};
+        if (MODE == 3) d[r] = normalise(d[r]);   // pre-test copy only: reflected directions drift off unit length
         moment[r] = scross(o, d[r]);
         unsafe |= !(fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))) <= sc.origin_bound);
     }
@@ -805,7 +790,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
         q_count = 0;
     };
 
-    const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_eye : sc.strip_any;
+    const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_eye : sc.sphere_any;
     for (uint32_t first = split.first_prim; first < split.end_prim; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), split.end_prim - first);
         __syncthreads();
@@ -814,15 +799,9 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
         for (uint32_t k = 0; k < count; ++k) {
             bool keep[R];
             bool any = keep_all;
-            if (MODE == 2) {
-                const float4 c = lds[k];
+            const float4 c = lds[k];
 #pragma unroll
-                for (int r = 0; r < R; ++r) { keep[r] = cone_keeps(d[r], c); any |= keep[r]; }
-            } else {
-                const float4 s0 = lds[k * 3], s1 = lds[k * 3 + 1], s2 = lds[k * 3 + 2];
-#pragma unroll
-                for (int r = 0; r < R; ++r) { keep[r] = strip_keeps_any(d[r], moment[r], s0, s1, s2); any |= keep[r]; }
-            }
+            for (int r = 0; r < R; ++r) { keep[r] = MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], c); any |= keep[r]; }
             if (__any(any)) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -1065,12 +1044,12 @@ DEV ShadowRay make_shadow_ray(const State& st, uint32_t slot, bool point, V3 lv)
 }
 
 // MODE 0: full test only; 2: cone pre-test (point lights only: lights first_light.. are point
-// lights, their cone records start at sc.cone_light); 3: strip pre-test for rays with their own
+// lights, their cone records start at sc.cone_light); 3: bounding-sphere pre-test for rays with their own
 // origin (any light).  Queue and drain as in k_closest_tri; a drained pair that blocks sets the
 // owner's bit in LDS, which the owner picks up after the drain.
 template <int R, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
-    constexpr int WORDS = MODE == 2 ? 1 : (MODE == 3 ? 3 : 4);
+    constexpr int WORDS = MODE == 0 ? 4 : 1;
     __shared__ float4 lds[TILE_PRIMS * WORDS];
     __shared__ uint32_t lds_queue[MODE == 0 ? 1 : (BLOCK / 64) * QCAP * 3];
     __shared__ uint32_t lds_blocked[BLOCK];   // bit r: ray r of that thread is blocked (set by drains)
@@ -1133,7 +1112,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
     unsigned long long wave_tests = 0;   // tests spent on still-undecided rays (wave-uniform)
     bool done = wave_done();
     const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_light + static_cast<size_t>(light - sc.has_directional) * sc.n_tri
-                                                      : (MODE == 3 ? sc.strip_any : sc.tri);
+                                                      : (MODE == 3 ? sc.sphere_any : sc.tri);
     for (uint32_t first = split.first_prim; first < split.end_prim; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), split.end_prim - first);
         if (__syncthreads_and(done)) break;
@@ -1160,15 +1139,9 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
                 for (uint32_t k = 0; k < count; ++k) {
                     bool keep[R];
                     bool any = keep_all;
-                    if (MODE == 2) {
-                        const float4 c = lds[k];
+                    const float4 c = lds[k];
 #pragma unroll
-                        for (int r = 0; r < R; ++r) { keep[r] = cone_keeps(d[r], c); any |= keep[r]; }
-                    } else {
-                        const float4 s0 = lds[k * 3], s1 = lds[k * 3 + 1], s2 = lds[k * 3 + 2];
-#pragma unroll
-                        for (int r = 0; r < R; ++r) { keep[r] = strip_keeps_any(d[r], moment[r], s0, s1, s2); any |= keep[r]; }
-                    }
+                    for (int r = 0; r < R; ++r) { keep[r] = MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], c); any |= keep[r]; }
                     if (__any(any)) {
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
@@ -1691,11 +1664,11 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &tri))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &trif))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri), &s->eye_records))) return fail(rc);
-    float4 *cone_light, *strip_any;
+    float4 *cone_light, *sphere_any;
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * desc->n_point_lights, &cone_light))) return fail(rc);
-    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 3, &strip_any))) return fail(rc);
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri), &sphere_any))) return fail(rc);
     d.cone_light = cone_light;
-    d.strip_any = strip_any;
+    d.sphere_any = sphere_any;
     {
         float b = 0.0f;
         for (int i = 0; i < 6; ++i) b = std::fmax(b, std::fabs(desc->bounding_box[i]));
@@ -1705,7 +1678,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * 6, &ell))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * desc->n_point_lights, &ell_light))) return fail(rc);
     if (d.n_tri) hipLaunchKernelGGL(k_prep_triangles, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, raw_tri, d.tri_nb, tri, trif);
-    if (d.n_tri) hipLaunchKernelGGL(k_prep_strip_any, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, tri, d.n_tri, d.origin_bound, strip_any);
+    if (d.n_tri) hipLaunchKernelGGL(k_prep_sphere, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, tri, d.n_tri, d.origin_bound, sphere_any);
     for (uint64_t l = 0; d.n_tri && l < desc->n_point_lights; ++l) {
         const float* L = desc->point_light_sources + l * 6;
         hipLaunchKernelGGL(k_prep_cone, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, tri, d.n_tri, L[0], L[1], L[2], d.origin_bound, 1,
