@@ -1,0 +1,46 @@
+"""Properties at the benchmark's full size (scene7 at 3840x2160), where the oracle is far too slow:
+the pre-tested scan equals the full-test scan on a centred region, a 4-way tile split assembles to the
+single-rank frame, and rendering is deterministic."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import scene_path
+from raytracer_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def test_scene7_4k_properties(gpu):
+    import torch
+    from raytracer_amd import distributed
+    fi = gpu.FileInfo(scene_path("scene7"))
+    fi.set_size(3840, 2160)
+    cam = fi.camera()
+    scene = gpu.Scene(fi.scene_desc)
+    whole = scene.render(cam, fi.params())
+    again = scene.render(cam, fi.params())
+    assert hashlib.sha256(whole["rgb"].tobytes()).digest() == hashlib.sha256(again["rgb"].tobytes()).digest()
+    st = whole["stats"]
+    assert st.samples == 3840 * 2160 * 16 and st.closest_tests[0] == st.closest_rays * 100000
+    assert st.shadow_rays == st.hits      # one point light
+
+    # the centre of the frame through the full test only
+    rect = dict(rect_x0=1600, rect_y0=896, rect_w=640, rect_h=368)
+    slow = scene.render(cam, fi.params(flags=abi.RT_FLAG_NO_FILTER, **rect), want_ids=True)
+    fast = scene.render(cam, fi.params(**rect), want_ids=True)
+    assert np.array_equal(slow["ids"], fast["ids"]) and np.array_equal(slow["rgb"], fast["rgb"])
+    assert np.array_equal(fast["rgb"], whole["rgb"][896:896 + 368, 1600:1600 + 640])
+
+    # four ranks' tile buffers, as the all-gather lays them out, assemble to the same frame
+    world = 4
+    stride = distributed.stride_tiles(fi.params(), world)
+    gathered = torch.zeros(world * stride * 768, dtype=torch.uint8, device="cuda:0")
+    for rank in range(world):
+        scene.render_tiles_device(cam, fi.params(tile_rank=rank, tile_world=world), gathered[rank * stride * 768:].data_ptr())
+    frame = torch.zeros(whole["rgb"].size, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    gpu.assemble_tiles_device(gathered.data_ptr(), stride, fi.params(tile_world=world), frame.data_ptr())
+    assert np.array_equal(frame.cpu().numpy().reshape(whole["rgb"].shape), whole["rgb"])
+    scene.close()
