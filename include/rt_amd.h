@@ -122,6 +122,7 @@ typedef struct rt_stats {
     uint64_t closest_launches;    /* launches timed in closest_ms */
     uint64_t shadow_launches;     /* launches timed in shadow_ms */
     uint64_t full_tests;          /* ray-triangle tests that went through the full test after the pre-test (0 with RT_FLAG_NO_FILTER) */
+    uint64_t pair_pretests[2];    /* ray-triangle pairs the per-wave (packet) pre-test left to the per-ray pre-test: closest-hit scans, shadow scans (0 with RT_FLAG_NO_FILTER) */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;          /* opaque: device-resident scene */

@@ -75,6 +75,7 @@ class Stats(C.Structure):
         ("closest_launches", C.c_uint64),
         ("shadow_launches", C.c_uint64),
         ("full_tests", C.c_uint64),
+        ("pair_pretests", C.c_uint64 * 2),
     ]
 
     def as_dict(self):

@@ -106,12 +106,14 @@ struct State {
     uint32_t* blocked;                    // bit l: light l of the current group is blocked
     uint32_t* list[2];                    // compacted slots of live rays, ping-pong
     uint32_t* counts;                     // counts[b]: live rays entering bounce b
+    unsigned long long* flag_bits;        // per producing workgroup: 4 wave ballots of "this entry goes on" (ordered compaction)
+    uint32_t* wg_offset;                  // per producing workgroup: position of its first entry in the next list
     uint32_t* primary_id;                 // nullable
     unsigned long long* stats;            // ST_* counters
 };
 
 enum { ST_SAMPLES, ST_CULLED, ST_CLOSEST_RAYS, ST_HITS, ST_SHADOW_RAYS, ST_SHADOW_BLOCKED,
-       ST_SHADOW_TESTS_TRI, ST_SHADOW_TESTS_SPH, ST_SHADOW_TESTS_ELL, ST_FULL_TESTS, ST_COUNT };
+       ST_SHADOW_TESTS_TRI, ST_SHADOW_TESTS_SPH, ST_SHADOW_TESTS_ELL, ST_FULL_TESTS, ST_PAIR_PRETESTS, ST_PAIR_PRETESTS_SHADOW, ST_COUNT };
 
 struct V3 { float x, y, z; };
 
@@ -286,6 +288,102 @@ DEV bool sphere_keeps(V3 d, V3 m, float4 c) {
     return !(q > c.w);
 }
 
+// Per-wave ("packet") pre-test, ahead of cone_keeps / sphere_keeps.  A wave's rays are neighbours
+// in the image, so they fit in a narrow bound: a cone of directions (unit axis A, cosine cw of the
+// half angle) and, for rays with their own origins, a ball (O, rho) around the origins.  One lane
+// tests one triangle record against the bound of the whole wave, so a triangle the wave cannot
+// reach costs 1/64 of a lane-instruction sequence instead of one per ray.
+//
+// Cone records (rays through a common point X): a ray of the wave hits the triangle only if its
+// direction lies in both cones, hence only if angle(A, axis) <= theta_w + theta_t, i.e.
+// A.axis >= cw*ct - sw*st.  1 - c*c is evaluated with one fused multiply-add, so the sines carry
+// a relative error of about 2^-23 even for cosines next to 1.  All roundings together (the two dot
+// products, |A| and |axis| off 1 by a few 2^-24, the products) stay below 1e-6 in the comparison;
+// cw is lowered by 1e-6 when it is formed and the threshold by another 2e-6.
+// Sphere records (c, r^2): moving every origin to O enlarges the sphere to r + rho; seen from O it
+// spans the half angle psi = asin((r + rho)/|c - O|), and the wave reaches it only if
+// angle(A, c - O) <= theta_w + psi.  sin(psi) is inflated by 2e-5 relative, which covers the
+// approximate sqrt/rsq (1 ulp each) and the rounding of its cosine.
+// Both tests need theta_w < 90 degrees (cw > 0), so that the angle sums stay below 180; a wider
+// wave, NaN or infinity anywhere keeps the triangle.
+struct Packet { V3 A; float cw, sw; V3 O; float rho, o1; };
+DEV float wave_sum(float v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+DEV float wave_min(float v) {
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+DEV float wave_max(float v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+// Bound of the wave's valid rays; d must be of unit length up to rounding.  o may be null (common point).
+template <int R>
+DEV Packet make_packet(const V3 (&d)[R], const V3* o, const bool (&valid)[R]) {
+    Packet p;
+    V3 sd{0.0f, 0.0f, 0.0f}, so{0.0f, 0.0f, 0.0f};
+    float n = 0.0f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (valid[r]) {
+            sd = add(sd, d[r]);
+            n += 1.0f;
+            if (o) so = add(so, o[r]);
+        }
+    }
+    sd = {wave_sum(sd.x), wave_sum(sd.y), wave_sum(sd.z)};
+    n = wave_sum(n);
+    p.A = normalise(sd);
+    float cw = 2.0f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) if (valid[r]) cw = fminf(cw, vdot(d[r], p.A));
+    cw = wave_min(cw) - 1.0e-6f;
+    // NaN (no valid ray, or directions that cancel) must end as "keep": fminf drops NaN operands, so test A itself
+    if (!(fabsf(p.A.x) <= 2.0f) || !(fabsf(p.A.y) <= 2.0f) || !(fabsf(p.A.z) <= 2.0f) || !(n > 0.0f)) cw = -1.0f;
+    p.cw = cw;
+    p.sw = __builtin_amdgcn_sqrtf(fmaxf(fma_(-cw, cw, 1.0f), 0.0f)) * 1.000001f;
+    p.O = {0.0f, 0.0f, 0.0f};
+    p.rho = 0.0f;
+    p.o1 = 0.0f;
+    if (o) {
+        const float inv_n = 1.0f / fmaxf(n, 1.0f);
+        so = {wave_sum(so.x) * inv_n, wave_sum(so.y) * inv_n, wave_sum(so.z) * inv_n};
+        float far2 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (valid[r]) { const V3 e = sub(o[r], so); far2 = fmaxf(far2, vdot(e, e)); }
+        }
+        far2 = wave_max(far2);
+        p.O = so;
+        p.o1 = fabsf(so.x) + fabsf(so.y) + fabsf(so.z);
+        // o - O is rounded per component by 2^-24 (|o| + |O|): four times that, on top of the relative slack
+        p.rho = fma_(__builtin_amdgcn_sqrtf(far2), 1.00001f, 4.8e-7f * p.o1);
+        if (!(far2 < 1.0e30f)) p.cw = -1.0f;
+    }
+    return p;
+}
+DEV bool packet_cone_keeps(const Packet& p, float4 c) {
+    const float along = vdot(p.A, xyz(c));
+    const float st = __builtin_amdgcn_sqrtf(fmaxf(fma_(-c.w, c.w, 1.0f), 0.0f)) * 1.000001f;
+    const float thr = fma_(p.cw, c.w, -(p.sw * st)) - 2.0e-6f;
+    return !(along < thr) || !(c.w > 0.0f) || !(p.cw > 0.0f);
+}
+DEV bool packet_sphere_keeps(const Packet& p, float4 c) {
+    const V3 v = sub(xyz(c), p.O);
+    const float len2 = vdot(v, v);
+    const float inv_len = __builtin_amdgcn_rsqf(len2);
+    // c - O is rounded per component by 2^-24 (|c| + |O|): the centre may be off by that much (four times it is added)
+    const float slack = 2.4e-7f * ((fabsf(c.x) + fabsf(c.y)) + (fabsf(c.z) + p.o1));
+    const float reach = (__builtin_amdgcn_sqrtf(c.w) + p.rho) + slack;
+    const float sin_psi = reach * inv_len * 1.00002f;
+    const float cos_psi = __builtin_amdgcn_sqrtf(fmaxf(fma_(-sin_psi, sin_psi, 1.0f), 0.0f));
+    const float thr = fma_(p.cw, cos_psi, -(p.sw * sin_psi)) - 2.0e-6f;
+    const float along = vdot(v, p.A) * inv_len;
+    return !(along < thr) || !(sin_psi < 1.0f) || !(p.cw > 0.0f);
+}
+
 // ray_tracing.cpp:169-206; the far root is replaced by the near one at :202 and that is kept
 DEV float hit_sphere(V3 o, V3 d, float4 s) {
     const V3 oc = sub(xyz(s), o);
@@ -360,24 +458,6 @@ DEV bool ellipsoid_blocks(V3 o, V3 d, float4 i0, float4 i1, float4 i2, bool poin
 // ------------------------------------------------------------------------------------------
 // workgroup helpers
 // ------------------------------------------------------------------------------------------
-// Order-preserving append of the flagged lanes of a 256-thread workgroup to a global list.
-// Returns this lane's position (only meaningful when flag is set).
-DEV uint32_t block_append(bool flag, uint32_t* counter, uint32_t* lds4 /* >= 5 words */) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long mask = __ballot(flag);
-    const uint32_t before = __popcll(mask & ((1ull << lane) - 1ull));
-    if (lane == 0) lds4[wave] = __popcll(mask);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
-        lds4[4] = total ? atomicAdd(counter, total) : 0u;
-    }
-    __syncthreads();
-    uint32_t offset = lds4[4];
-    for (uint32_t w = 0; w < wave; ++w) offset += lds4[w];
-    return offset + before;
-}
-
 DEV void block_add_stat(unsigned long long* stat, unsigned long long value) {
     // wave reduction, then one atomic per wave
     for (int off = 32; off > 0; off >>= 1) value += __shfl_down(value, off);
@@ -567,7 +647,6 @@ __global__ void __launch_bounds__(BLOCK) k_prep_ellipsoid_lights(const float4* _
 // k_primary: one thread per sample of the chunk
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLOCK) k_primary(Frame f, DevScene sc, State st, uint32_t first_tile_slot) {
-    __shared__ uint32_t lds_scan[8];
     const uint32_t s = blockIdx.x * BLOCK + threadIdx.x;   // the grid covers the chunk's samples exactly
     const uint32_t tile_slot = first_tile_slot + s / SAMPLES_PER_TILE;
     const uint32_t tile = tile_slot * f.tile_world + f.tile_rank;
@@ -610,10 +689,63 @@ __global__ void __launch_bounds__(BLOCK) k_primary(Frame f, DevScene sc, State s
     }
     if (live) st.key[s] = NO_HIT_KEY;
     if (st.primary_id) st.primary_id[s] = live ? RT_ID_MISS : RT_ID_CULLED;
-    const uint32_t pos = block_append(live, &st.counts[0], lds_scan);
-    if (live) st.list[0][pos] = s;
+    const unsigned long long live_mask = __ballot(live);    // list 0 is built from these by k_scan_flags + k_fill_list
+    if ((threadIdx.x & 63u) == 0) st.flag_bits[blockIdx.x * 4u + (threadIdx.x >> 6)] = live_mask;
     block_add_stat(&st.stats[ST_SAMPLES], inside ? 1ull : 0ull);
     block_add_stat(&st.stats[ST_CULLED], (inside && !live) ? 1ull : 0ull);
+}
+
+// ------------------------------------------------------------------------------------------
+// ordered compaction: the entries a kernel flagged (one ballot per wave) become the next list,
+// in the order of the entries themselves
+// ------------------------------------------------------------------------------------------
+// The order matters for speed, not for results: with it, consecutive list entries are neighbours
+// in the image, which is what makes the per-wave pre-test of the scans narrow.  (Appending with one
+// atomic per workgroup leaves the workgroups in their completion order, scattered over the part
+// of the image that is in flight.)
+// k_scan_flags: one workgroup; exclusive prefix of the per-workgroup flag counts, and the total.
+constexpr int SCAN_THREADS = 1024;
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_flags(State st, const uint32_t* __restrict__ n_in_ptr, uint32_t n_in_fixed, uint32_t* __restrict__ n_out) {
+    __shared__ uint32_t partial[SCAN_THREADS];
+    const uint32_t n_in = n_in_ptr ? *n_in_ptr : n_in_fixed;
+    const uint32_t n_wg = (n_in + BLOCK - 1) / BLOCK;
+    const uint32_t per = (n_wg + SCAN_THREADS - 1) / SCAN_THREADS;
+    const uint32_t begin = min(n_wg, threadIdx.x * per), end = min(n_wg, begin + per);
+    uint32_t sum = 0;
+    for (uint32_t g = begin; g < end; ++g) {
+        const ulonglong2 a = reinterpret_cast<const ulonglong2*>(st.flag_bits)[g * 2u], b = reinterpret_cast<const ulonglong2*>(st.flag_bits)[g * 2u + 1u];
+        sum += __popcll(a.x) + __popcll(a.y) + __popcll(b.x) + __popcll(b.y);
+    }
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t step = 1; step < SCAN_THREADS; step <<= 1) {      // inclusive Hillis-Steele scan
+        const uint32_t add = threadIdx.x >= step ? partial[threadIdx.x - step] : 0u;
+        __syncthreads();
+        partial[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t running = partial[threadIdx.x] - sum;
+    for (uint32_t g = begin; g < end; ++g) {
+        const ulonglong2 a = reinterpret_cast<const ulonglong2*>(st.flag_bits)[g * 2u], b = reinterpret_cast<const ulonglong2*>(st.flag_bits)[g * 2u + 1u];
+        st.wg_offset[g] = running;
+        running += __popcll(a.x) + __popcll(a.y) + __popcll(b.x) + __popcll(b.y);
+    }
+    if (threadIdx.x == SCAN_THREADS - 1) *n_out = partial[SCAN_THREADS - 1];
+}
+// k_fill_list: workgroup g places the flagged ones of entries g*256.. (the entry itself from list_in, or its index).
+__global__ void __launch_bounds__(BLOCK) k_fill_list(State st, const uint32_t* __restrict__ n_in_ptr, uint32_t n_in_fixed,
+                                                     const uint32_t* __restrict__ list_in, uint32_t* __restrict__ list_out) {
+    const uint32_t n_in = n_in_ptr ? *n_in_ptr : n_in_fixed;
+    const uint32_t base = blockIdx.x * BLOCK;
+    if (base >= n_in) return;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t pos = st.wg_offset[blockIdx.x];
+    for (uint32_t w = 0; w < wave; ++w) pos += __popcll(st.flag_bits[blockIdx.x * 4u + w]);
+    const unsigned long long mask = st.flag_bits[blockIdx.x * 4u + wave];
+    if ((mask >> lane) & 1ull) {
+        pos += __popcll(mask & ((1ull << lane) - 1ull));
+        list_out[pos] = list_in ? list_in[base + threadIdx.x] : base + threadIdx.x;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -758,29 +890,35 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
         return;
     }
 
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const WaveQueue q{lds_queue + wave * QCAP * 3, lds_queue + wave * QCAP * 3 + QCAP, lds_queue + wave * QCAP * 3 + 2 * QCAP};
     uint32_t q_count = 0, n_full = 0;
 
+    // a wave owns 64*R consecutive rays of the list, so that its packet bound is as narrow as the list allows
     uint32_t slot[R];
     bool valid[R];
     V3 d[R], moment[R];
+    Packet packet;
     bool unsafe = false;    // an origin outside the bound the sphere records were built for: keep everything
+    {
+        V3 o[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t i = base + r * BLOCK + threadIdx.x;
-        valid[r] = i < n_rays;
-        slot[r] = list_in[valid[r] ? i : base];
-        const V3 o{st.ox[slot[r]], st.oy[slot[r]], st.oz[slot[r]]};
-        d[r] = {st.dx[slot[r]], st.dy[slot[r]], st.dz[slot[r]]};
-        if (MODE == 3) d[r] = normalise(d[r]);   // pre-test copy only: reflected directions drift off unit length
-        moment[r] = scross(o, d[r]);
-        unsafe |= !(fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))) <= sc.origin_bound);
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = base + wave * (64 * R) + r * 64 + lane;
+            valid[r] = i < n_rays;
+            slot[r] = list_in[valid[r] ? i : base];
+            o[r] = {st.ox[slot[r]], st.oy[slot[r]], st.oz[slot[r]]};
+            d[r] = {st.dx[slot[r]], st.dy[slot[r]], st.dz[slot[r]]};
+            if (MODE == 3) d[r] = normalise(d[r]);   // pre-test copy only: reflected directions drift off unit length
+            moment[r] = scross(o[r], d[r]);
+            unsafe |= !(fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z))) <= sc.origin_bound);
+        }
+        packet = make_packet<R>(d, MODE == 3 ? o : nullptr, valid);
     }
     const bool keep_all = MODE == 3 && __any(unsafe);
 
     auto drain = [&]() {
-        for (uint32_t i = threadIdx.x & 63u; i < q_count; i += 64) {
+        for (uint32_t i = lane; i < q_count; i += 64) {
             const uint32_t s = q.slot[i], k = q.k[i];
             const V3 o{st.ox[s], st.oy[s], st.oz[s]};
             const V3 dd{st.dx[s], st.dy[s], st.dz[s]};
@@ -790,29 +928,39 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
         q_count = 0;
     };
 
+    uint32_t packet_kept = 0;
     const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_eye : sc.sphere_any;
     for (uint32_t first = split.first_prim; first < split.end_prim; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), split.end_prim - first);
         __syncthreads();
         stage_tile<WORDS>(lds, tri_stream, first, count);
         __syncthreads();
-        for (uint32_t k = 0; k < count; ++k) {
-            bool keep[R];
-            bool any = keep_all;
-            const float4 c = lds[k];
+        for (uint32_t k0 = 0; k0 < count; k0 += 64) {
+            const float4 mine = lds[k0 + lane];
+            const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine) : packet_sphere_keeps(packet, mine);
+            unsigned long long mask = __ballot((reach || keep_all) && k0 + lane < count);
+            packet_kept += __popcll(mask);
+            while (mask) {
+                const uint32_t k = k0 + static_cast<uint32_t>(__builtin_ctzll(mask));
+                mask &= mask - 1ull;
+                bool keep[R];
+                bool any = keep_all;
+                const float4 c = lds[k];
 #pragma unroll
-            for (int r = 0; r < R; ++r) { keep[r] = MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], c); any |= keep[r]; }
-            if (__any(any)) {
+                for (int r = 0; r < R; ++r) { keep[r] = MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], c); any |= keep[r]; }
+                if (__any(any)) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (q_count + 64 > QCAP) drain();
-                    queue_push(q, q_count, (keep[r] || keep_all) && valid[r], slot[r], first + k, 0u);
+                    for (int r = 0; r < R; ++r) {
+                        if (q_count + 64 > QCAP) drain();
+                        queue_push(q, q_count, (keep[r] || keep_all) && valid[r], slot[r], first + k, 0u);
+                    }
                 }
             }
         }
     }
     drain();
     block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
+    if (lane == 0 && packet_kept) atomicAdd(&st.stats[ST_PAIR_PRETESTS], static_cast<unsigned long long>(packet_kept) * (64 * R));
 }
 
 template <int R>
@@ -886,7 +1034,6 @@ __global__ void __launch_bounds__(BLOCK) k_closest_ell(DevScene sc, State st, ui
 // k_hit: one ray per thread.  Kind choice (ray_tracing.cpp:610-680), hit point, normal,
 // ambient + emission (:682), and the order-preserving list of rays that go on.
 __global__ void __launch_bounds__(BLOCK) k_hit(DevScene sc, State st, uint32_t bounce) {
-    __shared__ uint32_t lds_scan[8];
     const uint32_t n_rays = st.counts[bounce];
     const uint32_t base = blockIdx.x * BLOCK;
     if (base >= n_rays) return;
@@ -959,8 +1106,8 @@ __global__ void __launch_bounds__(BLOCK) k_hit(DevScene sc, State st, uint32_t b
         st.key[s] = NO_HIT_KEY;      // for the next bounce's triangle scan
         if (bounce == 0 && st.primary_id) st.primary_id[s] = id;
     }
-    const uint32_t pos = block_append(hit, &st.counts[bounce + 1], lds_scan);
-    if (hit) st.list[(bounce + 1) & 1u][pos] = s;
+    const unsigned long long hit_mask = __ballot(hit);      // the next list is built from these by k_scan_flags + k_fill_list
+    if ((threadIdx.x & 63u) == 0) st.flag_bits[blockIdx.x * 4u + (threadIdx.x >> 6)] = hit_mask;
     block_add_stat(&st.stats[ST_CLOSEST_RAYS], valid ? 1ull : 0ull);
     block_add_stat(&st.stats[ST_HITS], hit ? 1ull : 0ull);
 }
@@ -1069,20 +1216,27 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
     const bool point = L[0] != 0.0f;
     const V3 lv{L[1], L[2], L[3]};
 
+    // a wave owns 64*R consecutive rays of the list (see k_closest_tri)
     uint32_t slot[R];
     bool valid[R], blocked[R];
     V3 d[R], moment[R];
+    Packet packet;
     bool unsafe = false;
+    {
+        V3 o[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t i = base + r * BLOCK + threadIdx.x;
-        valid[r] = i < n_rays;
-        slot[r] = list_in[valid[r] ? i : base];
-        const ShadowRay s = make_shadow_ray(st, slot[r], point, lv);
-        d[r] = s.d;
-        moment[r] = scross(s.o, s.d);
-        unsafe |= !(fmaxf(fabsf(s.o.x), fmaxf(fabsf(s.o.y), fabsf(s.o.z))) <= sc.origin_bound);
-        blocked[r] = (st.blocked[slot[r]] & light_bit) != 0u;
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = base + (threadIdx.x >> 6) * (64 * R) + r * 64 + (threadIdx.x & 63u);
+            valid[r] = i < n_rays;
+            slot[r] = list_in[valid[r] ? i : base];
+            const ShadowRay s = make_shadow_ray(st, slot[r], point, lv);
+            o[r] = s.o;
+            d[r] = s.d;
+            moment[r] = scross(s.o, s.d);
+            unsafe |= !(fmaxf(fabsf(s.o.x), fmaxf(fabsf(s.o.y), fabsf(s.o.z))) <= sc.origin_bound);
+            blocked[r] = (st.blocked[slot[r]] & light_bit) != 0u;
+        }
+        if (MODE != 0) packet = make_packet<R>(d, MODE == 3 ? o : nullptr, valid);
     }
     lds_blocked[threadIdx.x] = 0u;
     const bool keep_all = MODE != 0 && __any(unsafe);
@@ -1110,6 +1264,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
     };
 
     unsigned long long wave_tests = 0;   // tests spent on still-undecided rays (wave-uniform)
+    uint32_t packet_kept = 0;
     bool done = wave_done();
     const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_light + static_cast<size_t>(light - sc.has_directional) * sc.n_tri
                                                       : (MODE == 3 ? sc.sphere_any : sc.tri);
@@ -1136,17 +1291,25 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
                     for (int r = 0; r < R; ++r) blocked[r] |= hit_triangle(o[r], d[r], t0, t1, t2, t3.x) < limit[r];
                 }
             } else {
-                for (uint32_t k = 0; k < count; ++k) {
-                    bool keep[R];
-                    bool any = keep_all;
-                    const float4 c = lds[k];
+                for (uint32_t k0 = 0; k0 < count; k0 += 64) {
+                    const float4 mine = lds[k0 + (threadIdx.x & 63u)];
+                    const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine) : packet_sphere_keeps(packet, mine);
+                    unsigned long long mask = __ballot((reach || keep_all) && k0 + (threadIdx.x & 63u) < count);
+                    packet_kept += __popcll(mask);
+                    while (mask) {
+                        const uint32_t k = k0 + static_cast<uint32_t>(__builtin_ctzll(mask));
+                        mask &= mask - 1ull;
+                        bool keep[R];
+                        bool any = keep_all;
+                        const float4 c = lds[k];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) { keep[r] = MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], c); any |= keep[r]; }
-                    if (__any(any)) {
+                        for (int r = 0; r < R; ++r) { keep[r] = MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], c); any |= keep[r]; }
+                        if (__any(any)) {
 #pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            if (q_count + 64 > QCAP) drain();
-                            queue_push(q, q_count, (keep[r] || keep_all) && valid[r] && !blocked[r], slot[r], first + k, (threadIdx.x << 8) | static_cast<uint32_t>(r));
+                            for (int r = 0; r < R; ++r) {
+                                if (q_count + 64 > QCAP) drain();
+                                queue_push(q, q_count, (keep[r] || keep_all) && valid[r] && !blocked[r], slot[r], first + k, (threadIdx.x << 8) | static_cast<uint32_t>(r));
+                            }
                         }
                     }
                 }
@@ -1160,6 +1323,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
         if (valid[r] && blocked[r]) atomicOr(&st.blocked[slot[r]], light_bit);
     if ((threadIdx.x & 63u) == 0 && wave_tests) atomicAdd(&st.stats[ST_SHADOW_TESTS_TRI], wave_tests);
     if (MODE != 0) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
+    if ((threadIdx.x & 63u) == 0 && packet_kept) atomicAdd(&st.stats[ST_PAIR_PRETESTS_SHADOW], static_cast<unsigned long long>(packet_kept) * (64 * R));
 }
 
 template <int R>
@@ -1412,7 +1576,8 @@ int ensure_state(size_t samples) {
     if (g_lib.state_samples >= samples) return 0;
     if (g_lib.state_mem) { HIP_TRY(hipFree(g_lib.state_mem)); g_lib.state_mem = nullptr; g_lib.state_samples = 0; }
     // 18 float arrays + hit_id + blocked + 2 lists + primary ids + 64-bit keys = 25 words per sample
-    HIP_TRY(hipMalloc(&g_lib.state_mem, samples * 25 * sizeof(float)));
+    // + per 256 samples: 4 wave ballots and one offset (ordered compaction)
+    HIP_TRY(hipMalloc(&g_lib.state_mem, samples * 25 * sizeof(float) + samples / BLOCK * 40));
     g_lib.state_samples = samples;
     return 0;
 }
@@ -1428,6 +1593,8 @@ State make_state(size_t samples, bool want_ids) {
     st.hit_id = u; st.blocked = u + samples; st.list[0] = u + 2 * samples; st.list[1] = u + 3 * samples;
     st.primary_id = want_ids ? u + 4 * samples : nullptr;
     st.key = reinterpret_cast<unsigned long long*>(u + 5 * samples);   // 8-byte aligned: samples is a multiple of 4096
+    st.flag_bits = st.key + samples;                                   // 16-byte aligned likewise
+    st.wg_offset = reinterpret_cast<uint32_t*>(st.flag_bits + samples / BLOCK * 4);
     st.counts = g_lib.counts;
     st.stats = g_lib.stats;
     return st;
@@ -1512,6 +1679,9 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         const uint32_t n_samples = n_tiles * SAMPLES_PER_TILE;
         HIP_TRY(hipMemsetAsync(g_lib.counts, 0, 64 * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(k_primary, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, f, sc, st, first);
+        hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(nullptr), n_samples, st.counts);
+        hipLaunchKernelGGL(k_fill_list, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, st, static_cast<const uint32_t*>(nullptr), n_samples,
+                           static_cast<const uint32_t*>(nullptr), st.list[0]);
         const uint32_t scan_blocks = ceil_div(n_samples, BLOCK * RAYS_PER_LANE);
         auto blocks_for = [&](int rays_per_lane) {   // worst-case ray blocks, and room for the split of a small launch
             const uint32_t blocks = ceil_div(n_samples, static_cast<uint32_t>(BLOCK * rays_per_lane));
@@ -1529,6 +1699,9 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                 if (sc.n_ell) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
             });
             hipLaunchKernelGGL(k_hit, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+            hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(st.counts + b), 0u, st.counts + b + 1);
+            hipLaunchKernelGGL(k_fill_list, dim3(ray_blocks), dim3(BLOCK), 0, stream, st, static_cast<const uint32_t*>(st.counts + b), 0u,
+                               static_cast<const uint32_t*>(st.list[b & 1u]), st.list[(b + 1) & 1u]);
             if (sc.n_lights == 0) {
                 hipLaunchKernelGGL(k_shade, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, st, b, 0u, 0u, 1u);
             } else {
@@ -1569,7 +1742,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         const uint64_t real_counts[3] = {sc.n_tri_mat, sc.n_sph_mat, sc.n_ell_mat};
         for (int k = 0; k < 3; ++k) stats->closest_tests[k] = stats->closest_rays * real_counts[k];
         stats->shadow_tests[0] = h[ST_SHADOW_TESTS_TRI]; stats->shadow_tests[1] = h[ST_SHADOW_TESTS_SPH]; stats->shadow_tests[2] = h[ST_SHADOW_TESTS_ELL];
-        stats->full_tests = h[ST_FULL_TESTS];
+        stats->full_tests = h[ST_FULL_TESTS]; stats->pair_pretests[0] = h[ST_PAIR_PRETESTS]; stats->pair_pretests[1] = h[ST_PAIR_PRETESTS_SHADOW];
         float ms = 0.0f;
         if (ev_begin && ev_end && hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) stats->device_ms = ms;
         double family_ms[2] = {0.0, 0.0};
