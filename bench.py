@@ -129,6 +129,7 @@ def main():
     local += [float(sum(s.closest_tests[k] for s in stats)) for k in range(3)]
     local += [float(sum(s.shadow_tests[k] for s in stats)) for k in range(3)]
     local += [float(sum(s.pair_pretests[k] for s in stats)) for k in range(2)]
+    local += [float(sum(s.queued_pairs[k] for s in stats)) for k in range(2)]
     local += [sum(s.closest_ms for s in stats), sum(s.shadow_ms for s in stats), sum(s.device_ms for s in stats)]
     local += [float(sum(s.closest_launches for s in stats)), float(sum(s.shadow_launches for s in stats))]
     acc = torch.tensor(local, dtype=torch.float64, device=device)
@@ -136,9 +137,9 @@ def main():
     if world > 1:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-    tot = dict(zip(fields + ["ct_tri", "ct_sph", "ct_ell", "st_tri", "st_sph", "st_ell", "pp_closest", "pp_shadow", "closest_ms", "shadow_ms", "device_ms",
+    tot = dict(zip(fields + ["ct_tri", "ct_sph", "ct_ell", "st_tri", "st_sph", "st_ell", "pp_closest", "pp_shadow", "q_closest", "q_shadow", "closest_ms", "shadow_ms", "device_ms",
                              "closest_launches", "shadow_launches"], acc.tolist()))
-    rank_max = dict(zip(["closest_ms", "shadow_ms", "device_ms"], mx.tolist()[15:18]))
+    rank_max = dict(zip(["closest_ms", "shadow_ms", "device_ms"], mx.tolist()[17:20]))
 
     if rank == 0:
         rays = tot["closest_rays"] + tot["shadow_rays"]
@@ -171,6 +172,7 @@ def main():
             "tests_per_step": tests / args.steps,
             "culled_samples_per_step": tot["culled"] / args.steps,
             "pair_pretests_per_step": [tot["pp_closest"] / args.steps, tot["pp_shadow"] / args.steps],
+            "queued_pairs_per_step": [tot["q_closest"] / args.steps, tot["q_shadow"] / args.steps],
             "full_tests_per_step": tot["full_tests"] / args.steps,
             "roofline": {
                 "bound": "valu_fp32",

@@ -123,6 +123,7 @@ typedef struct rt_stats {
     uint64_t shadow_launches;     /* launches timed in shadow_ms */
     uint64_t full_tests;          /* ray-triangle tests that went through the full test after the pre-test (0 with RT_FLAG_NO_FILTER) */
     uint64_t pair_pretests[2];    /* ray-triangle pairs the per-wave (packet) pre-test left to the per-ray pre-test: closest-hit scans, shadow scans (0 with RT_FLAG_NO_FILTER) */
+    uint64_t queued_pairs[2];     /* of which the per-ray pre-test kept (queued for the two-stage pre-test and the full test): closest-hit scans, shadow scans */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;          /* opaque: device-resident scene */

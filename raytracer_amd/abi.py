@@ -76,6 +76,7 @@ class Stats(C.Structure):
         ("shadow_launches", C.c_uint64),
         ("full_tests", C.c_uint64),
         ("pair_pretests", C.c_uint64 * 2),
+        ("queued_pairs", C.c_uint64 * 2),
     ]
 
     def as_dict(self):

@@ -113,7 +113,7 @@ struct State {
 };
 
 enum { ST_SAMPLES, ST_CULLED, ST_CLOSEST_RAYS, ST_HITS, ST_SHADOW_RAYS, ST_SHADOW_BLOCKED,
-       ST_SHADOW_TESTS_TRI, ST_SHADOW_TESTS_SPH, ST_SHADOW_TESTS_ELL, ST_FULL_TESTS, ST_PAIR_PRETESTS, ST_PAIR_PRETESTS_SHADOW, ST_COUNT };
+       ST_SHADOW_TESTS_TRI, ST_SHADOW_TESTS_SPH, ST_SHADOW_TESTS_ELL, ST_FULL_TESTS, ST_PAIR_PRETESTS, ST_PAIR_PRETESTS_SHADOW, ST_LIVE, ST_QUEUED, ST_QUEUED_SHADOW, ST_COUNT };
 
 struct V3 { float x, y, z; };
 
@@ -364,11 +364,21 @@ DEV Packet make_packet(const V3 (&d)[R], const V3* o, const bool (&valid)[R]) {
     }
     return p;
 }
+// The bound is the same in every lane; say so to the compiler (scalar registers).
+DEV Packet uniform_packet(Packet p) {
+    auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    p.A = {uni(p.A.x), uni(p.A.y), uni(p.A.z)};
+    p.cw = uni(p.cw); p.sw = uni(p.sw);
+    p.O = {uni(p.O.x), uni(p.O.y), uni(p.O.z)};
+    p.rho = uni(p.rho); p.o1 = uni(p.o1);
+    return p;
+}
 DEV bool packet_cone_keeps(const Packet& p, float4 c) {
+    // along >= cw*ct - sw*st, with x = along - cw*ct (+ slack):  x >= 0, or x^2 <= sw^2 st^2 = sw^2 (1 - ct^2)
     const float along = vdot(p.A, xyz(c));
-    const float st = __builtin_amdgcn_sqrtf(fmaxf(fma_(-c.w, c.w, 1.0f), 0.0f)) * 1.000001f;
-    const float thr = fma_(p.cw, c.w, -(p.sw * st)) - 2.0e-6f;
-    return !(along < thr) || !(c.w > 0.0f) || !(p.cw > 0.0f);
+    const float x = fma_(-p.cw, c.w, along) + 2.0e-6f;
+    const float rhs = (p.sw * p.sw) * (fma_(-c.w, c.w, 1.0f) * 1.00001f);
+    return !(x < 0.0f) || !(x * x > rhs) || !(c.w > 0.0f) || !(p.cw > 0.0f);
 }
 DEV bool packet_sphere_keeps(const Packet& p, float4 c) {
     const V3 v = sub(xyz(c), p.O);
@@ -643,6 +653,12 @@ __global__ void __launch_bounds__(BLOCK) k_prep_ellipsoid_lights(const float4* _
     }
 }
 
+// Pixels of a 16x16 tile are numbered along a Z curve, so that any 4, 16 or 64 consecutive pixels
+// form a 2x2, 4x4 or 8x8 block: rays that are neighbours in a list are neighbours in the image in
+// both directions, which keeps the packet bounds of the scans narrow.
+DEV uint32_t tile_pixel_x(uint32_t q) { return (q & 1u) | ((q >> 1) & 2u) | ((q >> 2) & 4u) | ((q >> 3) & 8u); }
+DEV uint32_t tile_pixel_y(uint32_t q) { return ((q >> 1) & 1u) | ((q >> 2) & 2u) | ((q >> 3) & 4u) | ((q >> 4) & 8u); }
+
 // ------------------------------------------------------------------------------------------
 // k_primary: one thread per sample of the chunk
 // ------------------------------------------------------------------------------------------
@@ -652,8 +668,8 @@ __global__ void __launch_bounds__(BLOCK) k_primary(Frame f, DevScene sc, State s
     const uint32_t tile = tile_slot * f.tile_world + f.tile_rank;
     const uint32_t in_tile = s % SAMPLES_PER_TILE;
     const uint32_t pixel = in_tile / RT_SAMPLES_PER_PIXEL, sample = in_tile % RT_SAMPLES_PER_PIXEL;
-    const uint32_t rx = (tile % f.tiles_x) * RT_TILE + pixel % RT_TILE;
-    const uint32_t ry = (tile / f.tiles_x) * RT_TILE + pixel / RT_TILE;
+    const uint32_t rx = (tile % f.tiles_x) * RT_TILE + tile_pixel_x(pixel);
+    const uint32_t ry = (tile / f.tiles_x) * RT_TILE + tile_pixel_y(pixel);
     const bool inside = rx < f.rect_w && ry < f.rect_h;
     const uint32_t x = f.rect_x0 + rx, y = f.rect_y0 + ry;
 
@@ -691,8 +707,6 @@ __global__ void __launch_bounds__(BLOCK) k_primary(Frame f, DevScene sc, State s
     if (st.primary_id) st.primary_id[s] = live ? RT_ID_MISS : RT_ID_CULLED;
     const unsigned long long live_mask = __ballot(live);    // list 0 is built from these by k_scan_flags + k_fill_list
     if ((threadIdx.x & 63u) == 0) st.flag_bits[blockIdx.x * 4u + (threadIdx.x >> 6)] = live_mask;
-    block_add_stat(&st.stats[ST_SAMPLES], inside ? 1ull : 0ull);
-    block_add_stat(&st.stats[ST_CULLED], (inside && !live) ? 1ull : 0ull);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -705,7 +719,7 @@ __global__ void __launch_bounds__(BLOCK) k_primary(Frame f, DevScene sc, State s
 // of the image that is in flight.)
 // k_scan_flags: one workgroup; exclusive prefix of the per-workgroup flag counts, and the total.
 constexpr int SCAN_THREADS = 1024;
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_flags(State st, const uint32_t* __restrict__ n_in_ptr, uint32_t n_in_fixed, uint32_t* __restrict__ n_out) {
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_flags(State st, const uint32_t* __restrict__ n_in_ptr, uint32_t n_in_fixed, uint32_t* __restrict__ n_out, int stat_in, int stat_out) {
     __shared__ uint32_t partial[SCAN_THREADS];
     const uint32_t n_in = n_in_ptr ? *n_in_ptr : n_in_fixed;
     const uint32_t n_wg = (n_in + BLOCK - 1) / BLOCK;
@@ -730,7 +744,12 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_flags(State st, const uin
         st.wg_offset[g] = running;
         running += __popcll(a.x) + __popcll(a.y) + __popcll(b.x) + __popcll(b.y);
     }
-    if (threadIdx.x == SCAN_THREADS - 1) *n_out = partial[SCAN_THREADS - 1];
+    if (threadIdx.x == SCAN_THREADS - 1) {
+        *n_out = partial[SCAN_THREADS - 1];
+        // the work counters that are list lengths are kept here: one atomic per launch instead of one per wave
+        if (stat_in >= 0) atomicAdd(&st.stats[stat_in], static_cast<unsigned long long>(n_in));
+        if (stat_out >= 0) atomicAdd(&st.stats[stat_out], static_cast<unsigned long long>(partial[SCAN_THREADS - 1]));
+    }
 }
 // k_fill_list: workgroup g places the flagged ones of entries g*256.. (the entry itself from list_in, or its index).
 __global__ void __launch_bounds__(BLOCK) k_fill_list(State st, const uint32_t* __restrict__ n_in_ptr, uint32_t n_in_fixed,
@@ -811,6 +830,24 @@ DEV ScanSplit scan_split(uint32_t n_rays, uint32_t rays_per_block, uint32_t n_pr
 // Candidate (ray, triangle) pairs a wave's first pre-test kept, queued in LDS and worked off one
 // pair per lane (drain).  This keeps the scan loop free of the registers the full test needs and
 // gives the rare full tests full lanes.
+// The pre-test scans read the 16-byte records straight from memory, one record per lane
+// (coalesced; the record arrays stay in L2), SCAN_UNROLL loads in flight per lane.  A record the
+// packet pre-test keeps is broadcast from the lane that holds it with v_readlane.  Waves are
+// independent: no LDS staging, no barriers in the scan.
+constexpr int SCAN_UNROLL = 4;
+constexpr uint32_t SCAN_STEP = 64 * SCAN_UNROLL;    // triangles per wave iteration
+constexpr uint32_t SHADOW_CHECK_STEPS = 4;          // shadow scans drain and re-check "all blocked" every so many iterations
+DEV float readlane_f(float v, uint32_t l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), static_cast<int>(l))); }
+DEV float4 readlane4(float4 v, uint32_t l) { return make_float4(readlane_f(v.x, l), readlane_f(v.y, l), readlane_f(v.z, l), readlane_f(v.w, l)); }
+// The lanes of a wave hand data to each other through LDS (queue entries, blocked bits).  The
+// hardware executes a wave's LDS operations in order, but the compiler reasons per thread: without
+// a fence it may keep a value one lane loaded earlier although another lane has changed it since.
+// wave_sync() orders the wave's memory operations as a barrier would, at no run-time cost.
+DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 constexpr uint32_t QCAP = 192;   // entries per wave; a push adds at most 64
 struct WaveQueue {
     uint32_t* slot;
@@ -842,8 +879,8 @@ DEV float pretests_then_full(const DevScene& sc, uint32_t k, V3 o, V3 d, uint32_
 // keeps are queued and drained through pretests_then_full.  Result: st.key[slot].
 template <int R, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, uint32_t bounce) {
-    constexpr int WORDS = MODE == 0 ? 4 : 1;
-    __shared__ float4 lds[TILE_PRIMS * WORDS];
+    constexpr int WORDS = 4;
+    __shared__ float4 lds[MODE == 0 ? TILE_PRIMS * WORDS : 1];   // record tiles, full-test mode only
     __shared__ uint32_t lds_queue[MODE == 0 ? 1 : (BLOCK / 64) * QCAP * 3];
     const uint32_t n_rays = st.counts[bounce];
     const uint32_t* __restrict__ list_in = st.list[bounce & 1u];
@@ -892,7 +929,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const WaveQueue q{lds_queue + wave * QCAP * 3, lds_queue + wave * QCAP * 3 + QCAP, lds_queue + wave * QCAP * 3 + 2 * QCAP};
-    uint32_t q_count = 0, n_full = 0;
+    uint32_t q_count = 0, n_full = 0, n_queued = 0;
 
     // a wave owns 64*R consecutive rays of the list, so that its packet bound is as narrow as the list allows
     uint32_t slot[R];
@@ -913,11 +950,12 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
             moment[r] = scross(o[r], d[r]);
             unsafe |= !(fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z))) <= sc.origin_bound);
         }
-        packet = make_packet<R>(d, MODE == 3 ? o : nullptr, valid);
+        packet = uniform_packet(make_packet<R>(d, MODE == 3 ? o : nullptr, valid));
     }
     const bool keep_all = MODE == 3 && __any(unsafe);
 
     auto drain = [&]() {
+        wave_sync();
         for (uint32_t i = lane; i < q_count; i += 64) {
             const uint32_t s = q.slot[i], k = q.k[i];
             const V3 o{st.ox[s], st.oy[s], st.oz[s]};
@@ -925,34 +963,36 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
             const float t = pretests_then_full(sc, k, o, dd, n_full);
             if (t < FLT_MAX) atomicMin(&st.key[s], pack_hit(t, k));
         }
+        wave_sync();
+        n_queued += q_count;
         q_count = 0;
     };
 
     uint32_t packet_kept = 0;
     const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_eye : sc.sphere_any;
-    for (uint32_t first = split.first_prim; first < split.end_prim; first += TILE_PRIMS) {
-        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), split.end_prim - first);
-        __syncthreads();
-        stage_tile<WORDS>(lds, tri_stream, first, count);
-        __syncthreads();
-        for (uint32_t k0 = 0; k0 < count; k0 += 64) {
-            const float4 mine = lds[k0 + lane];
-            const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine) : packet_sphere_keeps(packet, mine);
-            unsigned long long mask = __ballot((reach || keep_all) && k0 + lane < count);
+    for (uint32_t k0 = split.first_prim; k0 < split.end_prim; k0 += SCAN_STEP) {
+        float4 mine[SCAN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SCAN_UNROLL; ++u) mine[u] = tri_stream[min(k0 + u * 64 + lane, split.end_prim - 1u)];
+#pragma unroll
+        for (int u = 0; u < SCAN_UNROLL; ++u) {
+            const uint32_t ku = k0 + u * 64;
+            const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine[u]) : packet_sphere_keeps(packet, mine[u]);
+            unsigned long long mask = __ballot((reach || keep_all) && ku + lane < split.end_prim);
             packet_kept += __popcll(mask);
             while (mask) {
-                const uint32_t k = k0 + static_cast<uint32_t>(__builtin_ctzll(mask));
+                const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mask));
                 mask &= mask - 1ull;
+                const float4 c = readlane4(mine[u], bit);
                 bool keep[R];
                 bool any = keep_all;
-                const float4 c = lds[k];
 #pragma unroll
                 for (int r = 0; r < R; ++r) { keep[r] = MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], c); any |= keep[r]; }
                 if (__any(any)) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         if (q_count + 64 > QCAP) drain();
-                        queue_push(q, q_count, (keep[r] || keep_all) && valid[r], slot[r], first + k, 0u);
+                        queue_push(q, q_count, (keep[r] || keep_all) && valid[r], slot[r], ku + bit, 0u);
                     }
                 }
             }
@@ -961,6 +1001,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
     drain();
     block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
     if (lane == 0 && packet_kept) atomicAdd(&st.stats[ST_PAIR_PRETESTS], static_cast<unsigned long long>(packet_kept) * (64 * R));
+    if (lane == 0 && n_queued) atomicAdd(&st.stats[ST_QUEUED], static_cast<unsigned long long>(n_queued));
 }
 
 template <int R>
@@ -1108,8 +1149,6 @@ __global__ void __launch_bounds__(BLOCK) k_hit(DevScene sc, State st, uint32_t b
     }
     const unsigned long long hit_mask = __ballot(hit);      // the next list is built from these by k_scan_flags + k_fill_list
     if ((threadIdx.x & 63u) == 0) st.flag_bits[blockIdx.x * 4u + (threadIdx.x >> 6)] = hit_mask;
-    block_add_stat(&st.stats[ST_CLOSEST_RAYS], valid ? 1ull : 0ull);
-    block_add_stat(&st.stats[ST_HITS], hit ? 1ull : 0ull);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1196,8 +1235,8 @@ DEV ShadowRay make_shadow_ray(const State& st, uint32_t slot, bool point, V3 lv)
 // owner's bit in LDS, which the owner picks up after the drain.
 template <int R, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
-    constexpr int WORDS = MODE == 0 ? 4 : 1;
-    __shared__ float4 lds[TILE_PRIMS * WORDS];
+    constexpr int WORDS = 4;
+    __shared__ float4 lds[MODE == 0 ? TILE_PRIMS * WORDS : 1];   // record tiles, full-test mode only
     __shared__ uint32_t lds_queue[MODE == 0 ? 1 : (BLOCK / 64) * QCAP * 3];
     __shared__ uint32_t lds_blocked[BLOCK];   // bit r: ray r of that thread is blocked (set by drains)
     const uint32_t n_rays = st.counts[bounce + 1];
@@ -1236,9 +1275,10 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
             unsafe |= !(fmaxf(fabsf(s.o.x), fmaxf(fabsf(s.o.y), fabsf(s.o.z))) <= sc.origin_bound);
             blocked[r] = (st.blocked[slot[r]] & light_bit) != 0u;
         }
-        if (MODE != 0) packet = make_packet<R>(d, MODE == 3 ? o : nullptr, valid);
+        if (MODE != 0) packet = uniform_packet(make_packet<R>(d, MODE == 3 ? o : nullptr, valid));
     }
     lds_blocked[threadIdx.x] = 0u;
+    wave_sync();
     const bool keep_all = MODE != 0 && __any(unsafe);
     auto wave_done = [&]() {
         bool all = true;
@@ -1249,16 +1289,19 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
 
     const uint32_t wave = threadIdx.x >> 6;
     const WaveQueue q{lds_queue + wave * QCAP * 3, lds_queue + wave * QCAP * 3 + QCAP, lds_queue + wave * QCAP * 3 + 2 * QCAP};
-    uint32_t q_count = 0, n_full = 0;
+    uint32_t q_count = 0, n_full = 0, n_queued = 0;
     auto drain = [&]() {
+        wave_sync();
         for (uint32_t i = threadIdx.x & 63u; i < q_count; i += 64) {
             const uint32_t k = q.k[i], owner = q.owner[i];
             const ShadowRay s = make_shadow_ray(st, q.slot[i], point, lv);
             const float t = pretests_then_full(sc, k, s.o, s.d, n_full);
             if (t < s.limit) atomicOr(&lds_blocked[owner >> 8], 1u << (owner & 255u));
         }
+        wave_sync();
+        n_queued += q_count;
         q_count = 0;
-        const uint32_t mine = lds_blocked[threadIdx.x];
+        const uint32_t mine = __hip_atomic_load(&lds_blocked[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #pragma unroll
         for (int r = 0; r < R; ++r) blocked[r] |= ((mine >> r) & 1u) != 0u;
     };
@@ -1268,15 +1311,15 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
     bool done = wave_done();
     const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_light + static_cast<size_t>(light - sc.has_directional) * sc.n_tri
                                                       : (MODE == 3 ? sc.sphere_any : sc.tri);
-    for (uint32_t first = split.first_prim; first < split.end_prim; first += TILE_PRIMS) {
-        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), split.end_prim - first);
-        if (__syncthreads_and(done)) break;
-        stage_tile<WORDS>(lds, tri_stream, first, count);
-        __syncthreads();
-        if (!done) {
+    if (MODE == 0) {
+        for (uint32_t first = split.first_prim; first < split.end_prim; first += TILE_PRIMS) {
+            const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), split.end_prim - first);
+            if (__syncthreads_and(done)) break;
+            stage_tile<WORDS>(lds, tri_stream, first, count);
+            __syncthreads();
+            if (!done) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) wave_tests += static_cast<unsigned long long>(count) * __popcll(__ballot(valid[r] && !blocked[r]));
-            if (MODE == 0) {
+                for (int r = 0; r < R; ++r) wave_tests += static_cast<unsigned long long>(count) * __popcll(__ballot(valid[r] && !blocked[r]));
                 V3 o[R];
                 float limit[R];
 #pragma unroll
@@ -1290,33 +1333,49 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
 #pragma unroll
                     for (int r = 0; r < R; ++r) blocked[r] |= hit_triangle(o[r], d[r], t0, t1, t2, t3.x) < limit[r];
                 }
-            } else {
-                for (uint32_t k0 = 0; k0 < count; k0 += 64) {
-                    const float4 mine = lds[k0 + (threadIdx.x & 63u)];
-                    const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine) : packet_sphere_keeps(packet, mine);
-                    unsigned long long mask = __ballot((reach || keep_all) && k0 + (threadIdx.x & 63u) < count);
-                    packet_kept += __popcll(mask);
-                    while (mask) {
-                        const uint32_t k = k0 + static_cast<uint32_t>(__builtin_ctzll(mask));
-                        mask &= mask - 1ull;
-                        bool keep[R];
-                        bool any = keep_all;
-                        const float4 c = lds[k];
+                done = wave_done();
+            }
+        }
+    } else {
+        const uint32_t lane = threadIdx.x & 63u;
+        auto live_rays = [&]() {
+            uint32_t n = 0;
 #pragma unroll
-                        for (int r = 0; r < R; ++r) { keep[r] = MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], c); any |= keep[r]; }
-                        if (__any(any)) {
+            for (int r = 0; r < R; ++r) n += __popcll(__ballot(valid[r] && !blocked[r]));
+            return n;
+        };
+        uint32_t live = live_rays(), steps = 0;
+        for (uint32_t k0 = split.first_prim; k0 < split.end_prim && live != 0; k0 += SCAN_STEP) {
+            float4 mine[SCAN_UNROLL];
 #pragma unroll
-                            for (int r = 0; r < R; ++r) {
-                                if (q_count + 64 > QCAP) drain();
-                                queue_push(q, q_count, (keep[r] || keep_all) && valid[r] && !blocked[r], slot[r], first + k, (threadIdx.x << 8) | static_cast<uint32_t>(r));
-                            }
+            for (int u = 0; u < SCAN_UNROLL; ++u) mine[u] = tri_stream[min(k0 + u * 64 + lane, split.end_prim - 1u)];
+            wave_tests += static_cast<unsigned long long>(min(SCAN_STEP, split.end_prim - k0)) * live;
+#pragma unroll
+            for (int u = 0; u < SCAN_UNROLL; ++u) {
+                const uint32_t ku = k0 + u * 64;
+                const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine[u]) : packet_sphere_keeps(packet, mine[u]);
+                unsigned long long mask = __ballot((reach || keep_all) && ku + lane < split.end_prim);
+                packet_kept += __popcll(mask);
+                while (mask) {
+                    const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mask));
+                    mask &= mask - 1ull;
+                    const float4 c = readlane4(mine[u], bit);
+                    bool keep[R];
+                    bool any = keep_all;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) { keep[r] = MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], c); any |= keep[r]; }
+                    if (__any(any)) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            if (q_count + 64 > QCAP) drain();
+                            queue_push(q, q_count, (keep[r] || keep_all) && valid[r] && !blocked[r], slot[r], ku + bit, (threadIdx.x << 8) | static_cast<uint32_t>(r));
                         }
                     }
                 }
-                drain();
             }
-            done = wave_done();
+            if (++steps % SHADOW_CHECK_STEPS == 0) { drain(); live = live_rays(); }
         }
+        drain();
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -1324,6 +1383,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
     if ((threadIdx.x & 63u) == 0 && wave_tests) atomicAdd(&st.stats[ST_SHADOW_TESTS_TRI], wave_tests);
     if (MODE != 0) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
     if ((threadIdx.x & 63u) == 0 && packet_kept) atomicAdd(&st.stats[ST_PAIR_PRETESTS_SHADOW], static_cast<unsigned long long>(packet_kept) * (64 * R));
+    if ((threadIdx.x & 63u) == 0 && n_queued) atomicAdd(&st.stats[ST_QUEUED_SHADOW], static_cast<unsigned long long>(n_queued));
 }
 
 template <int R>
@@ -1470,7 +1530,8 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(State st, uint32_t first_tile
     for (uint32_t k = 0; k < RT_SAMPLES_PER_PIXEL; ++k) { r += st.cr[s0 + k]; g += st.cg[s0 + k]; b += st.cb[s0 + k]; }
     r = 0.0625f * r; g = 0.0625f * g; b = 0.0625f * b;                   // render_work_queue.cpp:51
     // truncating conversion, low byte kept: what the x86 build of render_work_queue.cpp:53-55 does
-    uint8_t* out = tiles_out + (static_cast<size_t>(first_tile_slot) * 256 + pixel) * 3;
+    const uint32_t in_tile = pixel % 256u;   // tile buffers are row-major, the samples are not (tile_pixel_x)
+    uint8_t* out = tiles_out + (static_cast<size_t>(first_tile_slot) * 256 + (pixel - in_tile) + tile_pixel_y(in_tile) * RT_TILE + tile_pixel_x(in_tile)) * 3;
     out[0] = static_cast<uint8_t>(static_cast<int>(r * 255.0f) & 0xFF);
     out[1] = static_cast<uint8_t>(static_cast<int>(g * 255.0f) & 0xFF);
     out[2] = static_cast<uint8_t>(static_cast<int>(b * 255.0f) & 0xFF);
@@ -1497,8 +1558,8 @@ __global__ void __launch_bounds__(BLOCK) k_scatter_ids(const uint32_t* __restric
     const uint32_t tile = (first_tile_slot + s / SAMPLES_PER_TILE) * f.tile_world + f.tile_rank;
     const uint32_t in_tile = s % SAMPLES_PER_TILE;
     const uint32_t pixel = in_tile / RT_SAMPLES_PER_PIXEL, sample = in_tile % RT_SAMPLES_PER_PIXEL;
-    const uint32_t rx = (tile % f.tiles_x) * RT_TILE + pixel % RT_TILE;
-    const uint32_t ry = (tile / f.tiles_x) * RT_TILE + pixel / RT_TILE;
+    const uint32_t rx = (tile % f.tiles_x) * RT_TILE + tile_pixel_x(pixel);
+    const uint32_t ry = (tile / f.tiles_x) * RT_TILE + tile_pixel_y(pixel);
     if (rx < f.rect_w && ry < f.rect_h) out[(static_cast<size_t>(ry) * f.rect_w + rx) * RT_SAMPLES_PER_PIXEL + sample] = chunk_ids[s];
 }
 
@@ -1679,7 +1740,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         const uint32_t n_samples = n_tiles * SAMPLES_PER_TILE;
         HIP_TRY(hipMemsetAsync(g_lib.counts, 0, 64 * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(k_primary, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, f, sc, st, first);
-        hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(nullptr), n_samples, st.counts);
+        hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(nullptr), n_samples, st.counts, -1, static_cast<int>(ST_LIVE));
         hipLaunchKernelGGL(k_fill_list, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, st, static_cast<const uint32_t*>(nullptr), n_samples,
                            static_cast<const uint32_t*>(nullptr), st.list[0]);
         const uint32_t scan_blocks = ceil_div(n_samples, BLOCK * RAYS_PER_LANE);
@@ -1699,7 +1760,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                 if (sc.n_ell) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
             });
             hipLaunchKernelGGL(k_hit, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-            hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(st.counts + b), 0u, st.counts + b + 1);
+            hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(st.counts + b), 0u, st.counts + b + 1,
+                               static_cast<int>(ST_CLOSEST_RAYS), static_cast<int>(ST_HITS));
             hipLaunchKernelGGL(k_fill_list, dim3(ray_blocks), dim3(BLOCK), 0, stream, st, static_cast<const uint32_t*>(st.counts + b), 0u,
                                static_cast<const uint32_t*>(st.list[b & 1u]), st.list[(b + 1) & 1u]);
             if (sc.n_lights == 0) {
@@ -1736,13 +1798,22 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         unsigned long long h[ST_COUNT];
         HIP_TRY(hipMemcpy(h, g_lib.stats, sizeof h, hipMemcpyDeviceToHost));
         std::memset(stats, 0, sizeof *stats);
-        stats->samples = h[ST_SAMPLES]; stats->culled = h[ST_CULLED];
+        // samples inside the rectangle, from the tile geometry; the bounding box culled those that are not live
+        unsigned long long inside = 0;
+        for (uint32_t t = prm->tile_rank; t < rect.tiles; t += world) {
+            const uint32_t tx = t % rect.tiles_x, ty = t / rect.tiles_x;
+            const uint32_t w = rect.w - tx * RT_TILE < RT_TILE ? rect.w - tx * RT_TILE : RT_TILE;
+            const uint32_t hh = rect.h - ty * RT_TILE < RT_TILE ? rect.h - ty * RT_TILE : RT_TILE;
+            inside += static_cast<unsigned long long>(w) * hh * RT_SAMPLES_PER_PIXEL;
+        }
+        stats->samples = inside; stats->culled = inside - h[ST_LIVE];
         stats->closest_rays = h[ST_CLOSEST_RAYS]; stats->hits = h[ST_HITS];
         stats->shadow_rays = h[ST_SHADOW_RAYS]; stats->shadow_blocked = h[ST_SHADOW_BLOCKED];
         const uint64_t real_counts[3] = {sc.n_tri_mat, sc.n_sph_mat, sc.n_ell_mat};
         for (int k = 0; k < 3; ++k) stats->closest_tests[k] = stats->closest_rays * real_counts[k];
         stats->shadow_tests[0] = h[ST_SHADOW_TESTS_TRI]; stats->shadow_tests[1] = h[ST_SHADOW_TESTS_SPH]; stats->shadow_tests[2] = h[ST_SHADOW_TESTS_ELL];
         stats->full_tests = h[ST_FULL_TESTS]; stats->pair_pretests[0] = h[ST_PAIR_PRETESTS]; stats->pair_pretests[1] = h[ST_PAIR_PRETESTS_SHADOW];
+        stats->queued_pairs[0] = h[ST_QUEUED]; stats->queued_pairs[1] = h[ST_QUEUED_SHADOW];
         float ms = 0.0f;
         if (ev_begin && ev_end && hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) stats->device_ms = ms;
         double family_ms[2] = {0.0, 0.0};

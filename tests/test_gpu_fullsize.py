@@ -22,6 +22,8 @@ def test_scene7_4k_properties(gpu):
     whole = scene.render(cam, fi.params())
     again = scene.render(cam, fi.params())
     assert hashlib.sha256(whole["rgb"].tobytes()).digest() == hashlib.sha256(again["rgb"].tobytes()).digest()
+    for f in ("closest_rays", "hits", "shadow_rays", "shadow_blocked"):
+        assert getattr(whole["stats"], f) == getattr(again["stats"], f), f
     st = whole["stats"]
     assert st.samples == 3840 * 2160 * 16 and st.closest_tests[0] == st.closest_rays * 100000
     assert st.shadow_rays == st.hits      # one point light
@@ -43,4 +45,27 @@ def test_scene7_4k_properties(gpu):
     torch.cuda.synchronize()
     gpu.assemble_tiles_device(gathered.data_ptr(), stride, fi.params(tile_world=world), frame.data_ptr())
     assert np.array_equal(frame.cpu().numpy().reshape(whole["rgb"].shape), whole["rgb"])
+    scene.close()
+
+
+@pytest.mark.gpu
+def test_scene7_whole_frames_fast_path_equals_full_test(gpu):
+    """Whole frames (no crop: the launch shapes of the bench), pre-tests on and off: same bytes, ids and ray counters.
+
+    The counters matter: one lost shadow-ray block changes a pixel by a few levels at most, and
+    16 samples per pixel can hide it; the blocked count cannot.
+    """
+    fi = gpu.FileInfo(scene_path("scene7"))
+    scene = gpu.Scene(fi.scene_desc)
+    for (w, h, depth) in ((1280, 720, 3), (1920, 1080, 1)):
+        fi.set_size(w, h)
+        cam = fi.camera()
+        fast = scene.render(cam, fi.params(max_bounce_count=depth), want_ids=True)
+        slow = scene.render(cam, fi.params(max_bounce_count=depth, flags=abi.RT_FLAG_NO_FILTER), want_ids=True)
+        again = scene.render(cam, fi.params(max_bounce_count=depth), want_ids=True)
+        for other in (slow, again):
+            for f in ("samples", "culled", "closest_rays", "hits", "shadow_rays", "shadow_blocked"):
+                assert getattr(fast["stats"], f) == getattr(other["stats"], f), (w, h, f)
+            assert np.array_equal(fast["ids"], other["ids"])
+            assert np.array_equal(fast["rgb"], other["rgb"])
     scene.close()
