@@ -24,12 +24,19 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(abi.PROTOTYPES) == names
 
 
-def test_struct_sizes_match_the_header():
-    # sizes the C compiler gives the structs of include/rt_amd.h on x86-64
-    assert C.sizeof(abi.SceneDesc) == 8 * 8 + 7 * 8 + (6 + 3 + 3 + 6) * 4 + 8
-    assert C.sizeof(abi.CameraDesc) == 14 * 4
-    assert C.sizeof(abi.RenderParams) == 12 * 4
-    assert C.sizeof(abi.Stats) == 6 * 8 + 6 * 8 + 3 * 8 + 3 * 8
+def test_struct_sizes_match_the_header(tmp_path):
+    """ctypes mirrors == what the C compiler makes of include/rt_amd.h (sizes and the offset of the last field)."""
+    import subprocess
+    src = tmp_path / "sizes.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "rt_amd.h"\n'
+        'int main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(rt_scene_desc), sizeof(rt_camera_desc), sizeof(rt_render_params),'
+        ' sizeof(rt_stats), offsetof(rt_stats, queued_pairs)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    sizes = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert sizes == [C.sizeof(abi.SceneDesc), C.sizeof(abi.CameraDesc), C.sizeof(abi.RenderParams), C.sizeof(abi.Stats),
+                     abi.Stats.queued_pairs.offset]
 
 
 def test_tile_partition_is_a_partition():
