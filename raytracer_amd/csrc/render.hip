@@ -19,6 +19,8 @@
 // the correctly rounded ones (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -57,6 +59,10 @@ namespace {
 constexpr float TOL = 1.0e-4f;            // maths.h:10
 constexpr int BLOCK = 256;                // threads per workgroup in every kernel
 constexpr int TILE_PRIMS = 256;           // primitives staged in LDS per step (triangles: 64 B each)
+#ifndef RT_CLUSTER
+#define RT_CLUSTER 16
+#endif
+constexpr uint32_t CLUSTER = RT_CLUSTER;          // triangles per cluster of the pre-test records
 constexpr uint32_t SAMPLES_PER_TILE = RT_TILE * RT_TILE * RT_SAMPLES_PER_PIXEL;  // 4096
 
 // Primitive lists are stored in "scan order": entry k holds the primitive the reference
@@ -66,9 +72,20 @@ constexpr uint32_t SAMPLES_PER_TILE = RT_TILE * RT_TILE * RT_SAMPLES_PER_PIXEL; 
 struct DevScene {
     const float4* tri;   // 4 x float4 per triangle: (a, n.x) (a_to_b, n.y) (a_to_c, n.z) (n.n, 0, 0, 0)
     const float4* trif;  // pre-test records, 4 x float4 per triangle, see pretest_stage1
-    const float4* cone_eye;     // cone records (1 x float4 per triangle) for rays from the camera eye, see cone_keeps
-    const float4* cone_light;   // [point light][triangle] cone records for shadow rays toward that light
-    const float4* sphere_any;   // bounding-sphere records (1 x float4 per triangle) for rays with their own origin, see sphere_keeps
+    // Pre-test records, 1 x float4 per triangle, in CLUSTER order: position s holds the triangle with scan index
+    // k_of[s]; consecutive positions are neighbours in space (sorted along a Z curve by the host at scene creation),
+    // and every CLUSTER consecutive positions have one record of the same kind that bounds them all.
+    const uint32_t* k_of;
+    const float4* cone_eye;     // cone records for rays from the camera eye, see cone_keeps
+    const float4* cone_light;   // [point light][position] cone records for shadow rays toward that light
+    const float4* sphere_any;   // bounding-sphere records for rays with their own origin, see sphere_keeps
+    const float4* cl_eye;       // [cluster] cone that contains the cones of its members
+    const float4* cl_light;     // [point light][cluster]
+    const float4* cl_sphere;    // [cluster] sphere that contains the spheres of its members
+    const float4* top_eye;      // [top node] the same one level up: a top node bounds CLUSTER consecutive clusters
+    const float4* top_light;    // [point light][top node]
+    const float4* top_sphere;
+    uint32_t n_clusters, n_tops;
     const float4* sph;   // (centre, radius)
     const float4* ell;   // 6 x float4: rows of the inverse transform, rows of the transform
     const float4* ell_light;  // [point light][ellipsoid]: inverse transform applied to the light position
@@ -516,10 +533,11 @@ __global__ void __launch_bounds__(BLOCK) k_prep_triangles(const float* __restric
 // about its centroid, where delta covers the hit point being slightly off the plane and, for
 // shadow rays, the rounding of the direction.  The cone is the one around the direction to the
 // centroid that contains the three scaled vertices, widened by asin(delta / distance).
-__global__ void __launch_bounds__(BLOCK) k_prep_cone(const float4* __restrict__ tri, uint32_t n_tri, float x, float y, float z,
+__global__ void __launch_bounds__(BLOCK) k_prep_cone(const float4* __restrict__ tri, const uint32_t* __restrict__ k_of, uint32_t n_tri, float x, float y, float z,
                                                      float origin_bound, int reversed, float4* __restrict__ out) {
-    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
-    if (k >= n_tri) return;
+    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
+    if (pos >= n_tri) return;
+    const uint32_t k = k_of[pos];
     const float4 t0 = tri[static_cast<size_t>(k) * 4], t1 = tri[static_cast<size_t>(k) * 4 + 1], t2 = tri[static_cast<size_t>(k) * 4 + 2], t3 = tri[static_cast<size_t>(k) * 4 + 3];
     const double a[3] = {t0.x, t0.y, t0.z}, n[3] = {t0.w, t1.w, t2.w}, ab[3] = {t1.x, t1.y, t1.z}, ac[3] = {t2.x, t2.y, t2.z};
     const double X[3] = {x, y, z};
@@ -578,15 +596,16 @@ __global__ void __launch_bounds__(BLOCK) k_prep_cone(const float4* __restrict__ 
             }
         }
     }
-    out[k] = rec;
+    out[pos] = rec;
 }
 
 // Bounding-sphere records (sphere_keeps) for rays whose origins lie within origin_bound of 0.
 // As in k_prep_cone: when the full test accepts, its hit point lies within delta of the triangle
 // scaled by (1 + 3m) about its centroid c.
-__global__ void __launch_bounds__(BLOCK) k_prep_sphere(const float4* __restrict__ tri, uint32_t n_tri, float origin_bound, float4* __restrict__ out) {
-    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
-    if (k >= n_tri) return;
+__global__ void __launch_bounds__(BLOCK) k_prep_sphere(const float4* __restrict__ tri, const uint32_t* __restrict__ k_of, uint32_t n_tri, float origin_bound, float4* __restrict__ out) {
+    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
+    if (pos >= n_tri) return;
+    const uint32_t k = k_of[pos];
     const float4 t0 = tri[static_cast<size_t>(k) * 4], t1 = tri[static_cast<size_t>(k) * 4 + 1], t2 = tri[static_cast<size_t>(k) * 4 + 2], t3 = tri[static_cast<size_t>(k) * 4 + 3];
     const double a[3] = {t0.x, t0.y, t0.z}, n[3] = {t0.w, t1.w, t2.w}, ab[3] = {t1.x, t1.y, t1.z}, ac[3] = {t2.x, t2.y, t2.z};
     const double nn = static_cast<double>(t3.x);
@@ -616,7 +635,79 @@ __global__ void __launch_bounds__(BLOCK) k_prep_sphere(const float4* __restrict_
         if (r2 < 1.0e30 && m < 1.0e6)
             rec = make_float4(static_cast<float>(c[0]), static_cast<float>(c[1]), static_cast<float>(c[2]), nextafterf(static_cast<float>(r2), __builtin_inff()));
     }
-    out[k] = rec;
+    out[pos] = rec;
+}
+
+// Cluster records: one thread per cluster, in double.
+// Cone: axis = normalised sum of the members' axes, half angle = max over members of (angle between
+// the axes + the member's half angle); a member that keeps every ray makes the cluster keep every
+// ray.  The cosine is lowered as in k_prep_cone for the rounding of the dot product in the kernel.
+// A direction inside a member's cone (as the kernel evaluates it) is then inside the cluster's.
+__global__ void __launch_bounds__(BLOCK) k_prep_cluster_cone(const float4* __restrict__ member, uint32_t n_tri, uint32_t n_clusters, float4* __restrict__ out) {
+    const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= n_clusters) return;
+    const uint32_t first = c * CLUSTER, count = min(CLUSTER, n_tri - first);
+    const double eps = 5.9604644775390625e-8;   // 2^-24
+    double sum[3] = {0.0, 0.0, 0.0};
+    bool all = false;
+    for (uint32_t t = 0; t < count; ++t) {
+        const float4 m = member[first + t];
+        if (!(m.w > -1.0f)) all = true;
+        sum[0] += m.x; sum[1] += m.y; sum[2] += m.z;
+    }
+    const double len = sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
+    float4 rec = make_float4(0.0f, 0.0f, 0.0f, -2.0f);   // keeps every ray
+    if (!all && len > 1.0e-3) {
+        const double axis[3] = {sum[0] / len, sum[1] / len, sum[2] / len};
+        double theta = 0.0;
+        for (uint32_t t = 0; t < count; ++t) {
+            const float4 m = member[first + t];
+            const double ml = sqrt(static_cast<double>(m.x) * m.x + static_cast<double>(m.y) * m.y + static_cast<double>(m.z) * m.z);
+            const double cosine = (axis[0] * m.x + axis[1] * m.y + axis[2] * m.z) / ml;
+            // the member's own cosine was lowered for its own evaluation; 16 eps more covers the member's axis being a rounded vector
+            theta = fmax(theta, acos(fmax(-1.0, fmin(1.0, cosine))) + acos(fmax(-1.0, fmin(1.0, static_cast<double>(m.w) - 16.0 * eps))));
+        }
+        theta += 1.0e-6;
+        if (theta < 1.5) {
+            const double cos_store = cos(theta) * (1.0 - 8.0 * eps) - 16.0 * eps;
+            rec = make_float4(static_cast<float>(axis[0]), static_cast<float>(axis[1]), static_cast<float>(axis[2]), nextafterf(static_cast<float>(cos_store), -2.0f));
+            if (!(rec.w > -1.0f && rec.w < 1.0f)) rec = make_float4(0.0f, 0.0f, 0.0f, -2.0f);
+        }
+    }
+    out[c] = rec;
+}
+// Sphere: centre = mean of the members' centres, radius = max over members of (distance of the
+// centres + the member's radius), then the same enlargements as in k_prep_sphere for the rounding of
+// the Pluecker expression with this centre.  A line within a member's radius of the member's centre
+// (as the kernel evaluates it) is then within the cluster's radius of the cluster's centre.
+__global__ void __launch_bounds__(BLOCK) k_prep_cluster_sphere(const float4* __restrict__ member, uint32_t n_tri, uint32_t n_clusters, float origin_bound, float4* __restrict__ out) {
+    const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= n_clusters) return;
+    const uint32_t first = c * CLUSTER, count = min(CLUSTER, n_tri - first);
+    const double eps = 5.9604644775390625e-8;   // 2^-24
+    double sum[3] = {0.0, 0.0, 0.0};
+    bool all = false;
+    for (uint32_t t = 0; t < count; ++t) {
+        const float4 m = member[first + t];
+        if (!(m.w < 1.0e30f)) all = true;
+        sum[0] += m.x; sum[1] += m.y; sum[2] += m.z;
+    }
+    float4 rec = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());   // keeps every ray
+    if (!all) {
+        const float cf[3] = {static_cast<float>(sum[0] / count), static_cast<float>(sum[1] / count), static_cast<float>(sum[2] / count)};
+        const double centre[3] = {cf[0], cf[1], cf[2]};   // the binary32 centre the kernel will use
+        double r = 0.0;
+        for (uint32_t t = 0; t < count; ++t) {
+            const float4 m = member[first + t];
+            const double e[3] = {m.x - centre[0], m.y - centre[1], m.z - centre[2]};
+            r = fmax(r, sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + sqrt(static_cast<double>(m.w)));
+        }
+        const double c_max = fmax(fabs(centre[0]), fmax(fabs(centre[1]), fabs(centre[2])));
+        const double r_tot = r * (1.0 + 1.0e-6) * (1.0 + 6.0 * eps) + 2.0 * 13.0 * eps * (c_max + origin_bound);
+        const double r2 = r_tot * r_tot * (1.0 + 1.0e-6);
+        if (r2 < 1.0e30) rec = make_float4(cf[0], cf[1], cf[2], nextafterf(static_cast<float>(r2), __builtin_inff()));
+    }
+    out[c] = rec;
 }
 
 __global__ void __launch_bounds__(BLOCK) k_prep_spheres(const float* __restrict__ sph8, uint32_t nb, float4* __restrict__ out) {
@@ -810,18 +901,19 @@ DEV void load_rays(const State& st, const uint32_t* __restrict__ list_in, uint32
 constexpr uint32_t SEG_TARGET = 4096;   // workgroups a small launch is spread over
 struct ScanSplit { uint32_t ray_base, first_prim, end_prim; bool active; };
 DEV ScanSplit scan_split(uint32_t n_rays, uint32_t rays_per_block, uint32_t n_prims) {
+    constexpr uint32_t STEP = 64;   // the list is the cluster list, walked 64 records (one per lane) at a time
     ScanSplit sp{0, 0, 0, false};
     const uint32_t n_blocks = (n_rays + rays_per_block - 1) / rays_per_block;
     if (n_blocks == 0) return sp;
-    const uint32_t n_tiles = (n_prims + TILE_PRIMS - 1) / TILE_PRIMS;
+    const uint32_t n_tiles = (n_prims + STEP - 1) / STEP;
     uint32_t segments = SEG_TARGET / n_blocks;
     segments = segments < 1 ? 1 : (segments > n_tiles ? n_tiles : segments);
     if (segments == 0 || blockIdx.x >= n_blocks * segments) return sp;
     const uint32_t tiles_per_segment = (n_tiles + segments - 1) / segments;
     const uint32_t seg = blockIdx.x % segments;
     sp.ray_base = (blockIdx.x / segments) * rays_per_block;
-    sp.first_prim = seg * tiles_per_segment * TILE_PRIMS;
-    sp.end_prim = min(n_prims, (seg + 1) * tiles_per_segment * TILE_PRIMS);
+    sp.first_prim = seg * tiles_per_segment * STEP;
+    sp.end_prim = min(n_prims, (seg + 1) * tiles_per_segment * STEP);
     sp.active = sp.first_prim < sp.end_prim;
     return sp;
 }
@@ -830,13 +922,10 @@ DEV ScanSplit scan_split(uint32_t n_rays, uint32_t rays_per_block, uint32_t n_pr
 // Candidate (ray, triangle) pairs a wave's first pre-test kept, queued in LDS and worked off one
 // pair per lane (drain).  This keeps the scan loop free of the registers the full test needs and
 // gives the rare full tests full lanes.
-// The pre-test scans read the 16-byte records straight from memory, one record per lane
-// (coalesced; the record arrays stay in L2), SCAN_UNROLL loads in flight per lane.  A record the
-// packet pre-test keeps is broadcast from the lane that holds it with v_readlane.  Waves are
-// independent: no LDS staging, no barriers in the scan.
-constexpr int SCAN_UNROLL = 4;
-constexpr uint32_t SCAN_STEP = 64 * SCAN_UNROLL;    // triangles per wave iteration
-constexpr uint32_t SHADOW_CHECK_STEPS = 4;          // shadow scans drain and re-check "all blocked" every so many iterations
+// The pre-test scans read the 16-byte cluster records straight from memory, one record per lane
+// (coalesced; the record arrays stay in L2).  A record the packet pre-test keeps is broadcast from
+// the lane that holds it with v_readlane.  Waves are independent: no LDS staging, no barriers.
+constexpr uint32_t SHADOW_CHECK_STEPS = 1;          // shadow scans drain and re-check "all blocked" every so many steps of 64 top nodes
 DEV float readlane_f(float v, uint32_t l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), static_cast<int>(l))); }
 DEV float4 readlane4(float4 v, uint32_t l) { return make_float4(readlane_f(v.x, l), readlane_f(v.y, l), readlane_f(v.z, l), readlane_f(v.w, l)); }
 // The lanes of a wave hand data to each other through LDS (queue entries, blocked bits).  The
@@ -848,18 +937,21 @@ DEV void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-constexpr uint32_t QCAP = 192;   // entries per wave; a push adds at most 64
-struct WaveQueue {
-    uint32_t* slot;
-    uint32_t* k;
-    uint32_t* owner;
-};
-DEV void queue_push(const WaveQueue& q, uint32_t& count, bool flag, uint32_t slot, uint32_t k, uint32_t owner) {
-    const unsigned long long mask = __ballot(flag);
+// Work queues of a wave, in LDS.  An entry is one word: (ray of the wave) << 24 | node, where
+// the ray is r*64 + lane of the lane that holds it (its slot is looked up in a per-wave table) and
+// the node is a top node, a cluster or a triangle position (hence at most 2^24 triangles).
+// A push adds up to 4 entries per lane.
+constexpr uint32_t QCAP = 384, PUSH_MAX = 256;
+constexpr uint32_t NODE_MASK = 0xFFFFFFu;
+// For every set bit b < n_bits of a lane's `bits`, append base + b*step.  Entries of one bit are contiguous, in lane order.
+DEV void push_bits(uint32_t* q, uint32_t& count, uint32_t bits, uint32_t n_bits, uint32_t base, uint32_t step) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t pos = count + __popcll(mask & ((1ull << lane) - 1ull));
-    if (flag) { q.slot[pos] = slot; q.k[pos] = k; q.owner[pos] = owner; }
-    count += __popcll(mask);
+    for (uint32_t b = 0; b < n_bits; ++b) {
+        const bool flag = ((bits >> b) & 1u) != 0u;
+        const unsigned long long mask = __ballot(flag);
+        if (flag) q[count + __popcll(mask & ((1ull << lane) - 1ull))] = base + b * step;
+        count += __popcll(mask);
+    }
 }
 
 // two-stage pre-test and, if it keeps the ray, the full test; FLT_MAX otherwise
@@ -881,14 +973,15 @@ template <int R, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, uint32_t bounce) {
     constexpr int WORDS = 4;
     __shared__ float4 lds[MODE == 0 ? TILE_PRIMS * WORDS : 1];   // record tiles, full-test mode only
-    __shared__ uint32_t lds_queue[MODE == 0 ? 1 : (BLOCK / 64) * QCAP * 3];
+    constexpr uint32_t WAVE_LDS = 3 * QCAP + 64 * R;   // per wave: (ray, top node), (ray, cluster) and (ray, triangle) queues, slot table
+    __shared__ uint32_t lds_queue[MODE == 0 ? 1 : (BLOCK / 64) * WAVE_LDS];
     const uint32_t n_rays = st.counts[bounce];
     const uint32_t* __restrict__ list_in = st.list[bounce & 1u];
     ScanSplit split;
     if (MODE == 0) {
         split = ScanSplit{blockIdx.x * (BLOCK * R), 0u, sc.n_tri, blockIdx.x * (BLOCK * R) < n_rays};
     } else {
-        split = scan_split(n_rays, BLOCK * R, sc.n_tri);
+        split = scan_split(n_rays, BLOCK * R, sc.n_tops);
     }
     if (!split.active) return;
     const uint32_t base = split.ray_base;
@@ -928,8 +1021,12 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
     }
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const WaveQueue q{lds_queue + wave * QCAP * 3, lds_queue + wave * QCAP * 3 + QCAP, lds_queue + wave * QCAP * 3 + 2 * QCAP};
-    uint32_t q_count = 0, n_full = 0, n_queued = 0;
+    uint32_t* const q0 = lds_queue + wave * WAVE_LDS;      // (ray, top node)
+    uint32_t* const q1 = q0 + QCAP;                        // (ray, cluster)
+    uint32_t* const q2 = q1 + QCAP;                        // (ray, triangle)
+    uint32_t* const wave_slots = q2 + QCAP;                // slot of ray r*64 + lane
+    uint32_t q0_count = 0, q1_count = 0, q2_count = 0, n_full = 0, n_queued = 0;
+    unsigned long long n_pairs = 0;
 
     // a wave owns 64*R consecutive rays of the list, so that its packet bound is as narrow as the list allows
     uint32_t slot[R];
@@ -949,58 +1046,91 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
             if (MODE == 3) d[r] = normalise(d[r]);   // pre-test copy only: reflected directions drift off unit length
             moment[r] = scross(o[r], d[r]);
             unsafe |= !(fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z))) <= sc.origin_bound);
+            wave_slots[r * 64 + lane] = slot[r];
         }
         packet = uniform_packet(make_packet<R>(d, MODE == 3 ? o : nullptr, valid));
     }
     const bool keep_all = MODE == 3 && __any(unsafe);
+    const float4* __restrict__ top_stream = MODE == 2 ? sc.top_eye : sc.top_sphere;
+    const float4* __restrict__ cluster_stream = MODE == 2 ? sc.cl_eye : sc.cl_sphere;
+    const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_eye : sc.sphere_any;
 
-    auto drain = [&]() {
+    // (ray, triangle) pairs: two-stage pre-test and full test, one pair per lane
+    auto drain2 = [&]() {
         wave_sync();
-        for (uint32_t i = lane; i < q_count; i += 64) {
-            const uint32_t s = q.slot[i], k = q.k[i];
+        for (uint32_t i = lane; i < q2_count; i += 64) {
+            const uint32_t e = q2[i];
+            const uint32_t s = wave_slots[e >> 24], k = sc.k_of[e & NODE_MASK];
             const V3 o{st.ox[s], st.oy[s], st.oz[s]};
             const V3 dd{st.dx[s], st.dy[s], st.dz[s]};
             const float t = pretests_then_full(sc, k, o, dd, n_full);
             if (t < FLT_MAX) atomicMin(&st.key[s], pack_hit(t, k));
         }
         wave_sync();
-        n_queued += q_count;
-        q_count = 0;
+        n_queued += q2_count;
+        q2_count = 0;
     };
-
-    uint32_t packet_kept = 0;
-    const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_eye : sc.sphere_any;
-    for (uint32_t k0 = split.first_prim; k0 < split.end_prim; k0 += SCAN_STEP) {
-        float4 mine[SCAN_UNROLL];
+    // (ray, node) pairs: one pair per lane, the lane walks the CLUSTER children of its node and queues
+    // the ones its ray may reach one level down
+    auto walk = [&](uint32_t* q_in, uint32_t& in_count, const float4* __restrict__ child, uint32_t n_child,
+                    uint32_t* q_out, uint32_t& out_count, auto&& drain_out) {
+        wave_sync();
+        for (uint32_t i0 = 0; i0 < in_count; i0 += 64) {
+            const bool active = i0 + lane < in_count;
+            const uint32_t e = q_in[active ? i0 + lane : 0u];
+            const uint32_t s = wave_slots[e >> 24], first = (e & NODE_MASK) * CLUSTER;
+            const V3 o{st.ox[s], st.oy[s], st.oz[s]};
+            V3 dd{st.dx[s], st.dy[s], st.dz[s]};
+            if (MODE == 3) dd = normalise(dd);
+            const V3 mm = scross(o, dd);
+            const uint32_t last = n_child - 1u;
+#pragma nounroll
+            for (uint32_t t0 = 0; t0 < CLUSTER; t0 += 4) {     // not unrolled: one copy of the code behind drain_out
+                float4 rec[4];
 #pragma unroll
-        for (int u = 0; u < SCAN_UNROLL; ++u) mine[u] = tri_stream[min(k0 + u * 64 + lane, split.end_prim - 1u)];
+                for (int u = 0; u < 4; ++u) rec[u] = child[min(first + t0 + u, last)];
+                uint32_t keep_bits = 0;
 #pragma unroll
-        for (int u = 0; u < SCAN_UNROLL; ++u) {
-            const uint32_t ku = k0 + u * 64;
-            const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine[u]) : packet_sphere_keeps(packet, mine[u]);
-            unsigned long long mask = __ballot((reach || keep_all) && ku + lane < split.end_prim);
-            packet_kept += __popcll(mask);
-            while (mask) {
-                const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mask));
-                mask &= mask - 1ull;
-                const float4 c = readlane4(mine[u], bit);
-                bool keep[R];
-                bool any = keep_all;
-#pragma unroll
-                for (int r = 0; r < R; ++r) { keep[r] = MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], c); any |= keep[r]; }
-                if (__any(any)) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        if (q_count + 64 > QCAP) drain();
-                        queue_push(q, q_count, (keep[r] || keep_all) && valid[r], slot[r], ku + bit, 0u);
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    const bool keep = active && first + t0 + u <= last && ((MODE == 2 ? cone_keeps(dd, rec[u]) : sphere_keeps(dd, mm, rec[u])) || keep_all);
+                    keep_bits |= keep ? 1u << u : 0u;
+                }
+                if (__any(keep_bits != 0u)) {
+                    if (out_count + PUSH_MAX > QCAP) drain_out();
+                    push_bits(q_out, out_count, keep_bits, 4u, (e & ~NODE_MASK) | (first + t0), 1u);
                 }
             }
         }
+        n_pairs += static_cast<unsigned long long>(in_count) * CLUSTER;
+        wave_sync();
+        in_count = 0;
+    };
+    auto drain1 = [&]() { walk(q1, q1_count, tri_stream, sc.n_tri, q2, q2_count, drain2); };
+    auto drain0 = [&]() { walk(q0, q0_count, cluster_stream, sc.n_clusters, q1, q1_count, drain1); };
+
+    wave_sync();
+    for (uint32_t c0 = split.first_prim; c0 < split.end_prim; c0 += 64) {
+        const float4 mine = top_stream[min(c0 + lane, split.end_prim - 1u)];
+        const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine) : packet_sphere_keeps(packet, mine);
+        unsigned long long mask = __ballot((reach || keep_all) && c0 + lane < split.end_prim);
+        while (mask) {
+            const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mask));
+            mask &= mask - 1ull;
+            const float4 c = readlane4(mine, bit);
+            uint32_t keep_bits = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) keep_bits |= ((MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], c)) || keep_all) && valid[r] ? 1u << r : 0u;
+            if (__any(keep_bits != 0u)) {
+                if (q0_count + PUSH_MAX > QCAP) drain0();
+                push_bits(q0, q0_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
+            }
+        }
     }
-    drain();
+    drain0();
+    drain1();
+    drain2();
     block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
-    if (lane == 0 && packet_kept) atomicAdd(&st.stats[ST_PAIR_PRETESTS], static_cast<unsigned long long>(packet_kept) * (64 * R));
+    if (lane == 0 && n_pairs) atomicAdd(&st.stats[ST_PAIR_PRETESTS], n_pairs);
     if (lane == 0 && n_queued) atomicAdd(&st.stats[ST_QUEUED], static_cast<unsigned long long>(n_queued));
 }
 
@@ -1237,14 +1367,15 @@ template <int R, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
     constexpr int WORDS = 4;
     __shared__ float4 lds[MODE == 0 ? TILE_PRIMS * WORDS : 1];   // record tiles, full-test mode only
-    __shared__ uint32_t lds_queue[MODE == 0 ? 1 : (BLOCK / 64) * QCAP * 3];
+    constexpr uint32_t WAVE_LDS = 3 * QCAP + 64 * R;   // per wave: (ray, top node), (ray, cluster) and (ray, triangle) queues, slot table
+    __shared__ uint32_t lds_queue[MODE == 0 ? 1 : (BLOCK / 64) * WAVE_LDS];
     __shared__ uint32_t lds_blocked[BLOCK];   // bit r: ray r of that thread is blocked (set by drains)
     const uint32_t n_rays = st.counts[bounce + 1];
     ScanSplit split;
     if (MODE == 0) {
         split = ScanSplit{blockIdx.x * (BLOCK * R), 0u, sc.n_tri, blockIdx.x * (BLOCK * R) < n_rays};
     } else {
-        split = scan_split(n_rays, BLOCK * R, sc.n_tri);
+        split = scan_split(n_rays, BLOCK * R, sc.n_tops);
     }
     if (!split.active) return;
     const uint32_t base = split.ray_base;
@@ -1274,6 +1405,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
             moment[r] = scross(s.o, s.d);
             unsafe |= !(fmaxf(fabsf(s.o.x), fmaxf(fabsf(s.o.y), fabsf(s.o.z))) <= sc.origin_bound);
             blocked[r] = (st.blocked[slot[r]] & light_bit) != 0u;
+            if (MODE != 0) lds_queue[(threadIdx.x >> 6) * WAVE_LDS + 3 * QCAP + r * 64 + (threadIdx.x & 63u)] = slot[r];
         }
         if (MODE != 0) packet = uniform_packet(make_packet<R>(d, MODE == 3 ? o : nullptr, valid));
     }
@@ -1287,27 +1419,76 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
         return __all(all) != 0;
     };
 
-    const uint32_t wave = threadIdx.x >> 6;
-    const WaveQueue q{lds_queue + wave * QCAP * 3, lds_queue + wave * QCAP * 3 + QCAP, lds_queue + wave * QCAP * 3 + 2 * QCAP};
-    uint32_t q_count = 0, n_full = 0, n_queued = 0;
-    auto drain = [&]() {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t* const q0 = lds_queue + wave * WAVE_LDS;      // (ray, top node)
+    uint32_t* const q1 = q0 + QCAP;                        // (ray, cluster)
+    uint32_t* const q2 = q1 + QCAP;                        // (ray, triangle)
+    uint32_t* const wave_slots = q2 + QCAP;                // slot of ray r*64 + lane
+    uint32_t q0_count = 0, q1_count = 0, q2_count = 0, n_full = 0, n_queued = 0;
+    unsigned long long n_pairs = 0;
+    const size_t light_index = MODE == 2 ? light - sc.has_directional : 0u;
+    const float4* __restrict__ top_stream = MODE == 2 ? sc.top_light + light_index * sc.n_tops : sc.top_sphere;
+    const float4* __restrict__ cluster_stream = MODE == 2 ? sc.cl_light + light_index * sc.n_clusters : sc.cl_sphere;
+    const float4* __restrict__ member_stream = MODE == 2 ? sc.cone_light + static_cast<size_t>(light - sc.has_directional) * sc.n_tri : sc.sphere_any;
+    // blocked bits of the wave's rays live in lds_blocked[thread that holds the ray], bit r; ray = r*64 + lane
+    auto ray_blocked = [&](uint32_t ray) {
+        return ((__hip_atomic_load(&lds_blocked[wave * 64u + (ray & 63u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> (ray >> 6)) & 1u) != 0u;
+    };
+    // (ray, triangle) pairs: two-stage pre-test and full test, one pair per lane; a pair that blocks sets its ray's bit
+    auto drain2 = [&]() {
         wave_sync();
-        for (uint32_t i = threadIdx.x & 63u; i < q_count; i += 64) {
-            const uint32_t k = q.k[i], owner = q.owner[i];
-            const ShadowRay s = make_shadow_ray(st, q.slot[i], point, lv);
+        for (uint32_t i = lane; i < q2_count; i += 64) {
+            const uint32_t e = q2[i];
+            const uint32_t ray = e >> 24, k = sc.k_of[e & NODE_MASK];
+            const ShadowRay s = make_shadow_ray(st, wave_slots[ray], point, lv);
             const float t = pretests_then_full(sc, k, s.o, s.d, n_full);
-            if (t < s.limit) atomicOr(&lds_blocked[owner >> 8], 1u << (owner & 255u));
+            if (t < s.limit) atomicOr(&lds_blocked[wave * 64u + (ray & 63u)], 1u << (ray >> 6));
         }
         wave_sync();
-        n_queued += q_count;
-        q_count = 0;
+        n_queued += q2_count;
+        q2_count = 0;
         const uint32_t mine = __hip_atomic_load(&lds_blocked[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #pragma unroll
         for (int r = 0; r < R; ++r) blocked[r] |= ((mine >> r) & 1u) != 0u;
     };
+    // (ray, node) pairs: one pair per lane, the lane walks the CLUSTER children of its node and queues
+    // the ones its ray may reach one level down; pairs of rays that are blocked by now are dropped
+    auto walk = [&](uint32_t* q_in, uint32_t& in_count, const float4* __restrict__ child, uint32_t n_child,
+                    uint32_t* q_out, uint32_t& out_count, auto&& drain_out) {
+        wave_sync();
+        for (uint32_t i0 = 0; i0 < in_count; i0 += 64) {
+            bool active = i0 + lane < in_count;
+            const uint32_t e = q_in[active ? i0 + lane : 0u];
+            const uint32_t first = (e & NODE_MASK) * CLUSTER;
+            active = active && !ray_blocked(e >> 24);
+            const ShadowRay s = make_shadow_ray(st, wave_slots[e >> 24], point, lv);
+            const V3 mm = scross(s.o, s.d);
+            const uint32_t last = n_child - 1u;
+#pragma nounroll
+            for (uint32_t t0 = 0; t0 < CLUSTER; t0 += 4) {     // not unrolled: one copy of the code behind drain_out
+                float4 rec[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rec[u] = child[min(first + t0 + u, last)];
+                uint32_t keep_bits = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool keep = active && first + t0 + u <= last && ((MODE == 2 ? cone_keeps(s.d, rec[u]) : sphere_keeps(s.d, mm, rec[u])) || keep_all);
+                    keep_bits |= keep ? 1u << u : 0u;
+                }
+                if (__any(keep_bits != 0u)) {
+                    if (out_count + PUSH_MAX > QCAP) drain_out();
+                    push_bits(q_out, out_count, keep_bits, 4u, (e & ~NODE_MASK) | (first + t0), 1u);
+                }
+            }
+        }
+        n_pairs += static_cast<unsigned long long>(in_count) * CLUSTER;
+        wave_sync();
+        in_count = 0;
+    };
+    auto drain1 = [&]() { walk(q1, q1_count, member_stream, sc.n_tri, q2, q2_count, drain2); };
+    auto drain0 = [&]() { walk(q0, q0_count, cluster_stream, sc.n_clusters, q1, q1_count, drain1); };
 
     unsigned long long wave_tests = 0;   // tests spent on still-undecided rays (wave-uniform)
-    uint32_t packet_kept = 0;
     bool done = wave_done();
     const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_light + static_cast<size_t>(light - sc.has_directional) * sc.n_tri
                                                       : (MODE == 3 ? sc.sphere_any : sc.tri);
@@ -1337,7 +1518,6 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
             }
         }
     } else {
-        const uint32_t lane = threadIdx.x & 63u;
         auto live_rays = [&]() {
             uint32_t n = 0;
 #pragma unroll
@@ -1345,44 +1525,33 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
             return n;
         };
         uint32_t live = live_rays(), steps = 0;
-        for (uint32_t k0 = split.first_prim; k0 < split.end_prim && live != 0; k0 += SCAN_STEP) {
-            float4 mine[SCAN_UNROLL];
+        for (uint32_t c0 = split.first_prim; c0 < split.end_prim && live != 0; c0 += 64) {
+            const float4 mine = top_stream[min(c0 + lane, split.end_prim - 1u)];
+            wave_tests += static_cast<unsigned long long>(min(sc.n_tri, min(c0 + 64u, split.end_prim) * (CLUSTER * CLUSTER)) - c0 * (CLUSTER * CLUSTER)) * live;
+            const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine) : packet_sphere_keeps(packet, mine);
+            unsigned long long mask = __ballot((reach || keep_all) && c0 + lane < split.end_prim);
+            while (mask) {
+                const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mask));
+                mask &= mask - 1ull;
+                const float4 c = readlane4(mine, bit);
+                uint32_t keep_bits = 0;
 #pragma unroll
-            for (int u = 0; u < SCAN_UNROLL; ++u) mine[u] = tri_stream[min(k0 + u * 64 + lane, split.end_prim - 1u)];
-            wave_tests += static_cast<unsigned long long>(min(SCAN_STEP, split.end_prim - k0)) * live;
-#pragma unroll
-            for (int u = 0; u < SCAN_UNROLL; ++u) {
-                const uint32_t ku = k0 + u * 64;
-                const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine[u]) : packet_sphere_keeps(packet, mine[u]);
-                unsigned long long mask = __ballot((reach || keep_all) && ku + lane < split.end_prim);
-                packet_kept += __popcll(mask);
-                while (mask) {
-                    const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mask));
-                    mask &= mask - 1ull;
-                    const float4 c = readlane4(mine[u], bit);
-                    bool keep[R];
-                    bool any = keep_all;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) { keep[r] = MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], c); any |= keep[r]; }
-                    if (__any(any)) {
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            if (q_count + 64 > QCAP) drain();
-                            queue_push(q, q_count, (keep[r] || keep_all) && valid[r] && !blocked[r], slot[r], ku + bit, (threadIdx.x << 8) | static_cast<uint32_t>(r));
-                        }
-                    }
+                for (int r = 0; r < R; ++r) keep_bits |= ((MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], c)) || keep_all) && valid[r] && !blocked[r] ? 1u << r : 0u;
+                if (__any(keep_bits != 0u)) {
+                    if (q0_count + PUSH_MAX > QCAP) drain0();
+                    push_bits(q0, q0_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
                 }
             }
-            if (++steps % SHADOW_CHECK_STEPS == 0) { drain(); live = live_rays(); }
+            // work the queues off before looking at "all blocked"; the last step does it for the whole scan
+            if (++steps % SHADOW_CHECK_STEPS == 0 || c0 + 64 >= split.end_prim) { drain0(); drain1(); drain2(); live = live_rays(); }
         }
-        drain();
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if (valid[r] && blocked[r]) atomicOr(&st.blocked[slot[r]], light_bit);
     if ((threadIdx.x & 63u) == 0 && wave_tests) atomicAdd(&st.stats[ST_SHADOW_TESTS_TRI], wave_tests);
     if (MODE != 0) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
-    if ((threadIdx.x & 63u) == 0 && packet_kept) atomicAdd(&st.stats[ST_PAIR_PRETESTS_SHADOW], static_cast<unsigned long long>(packet_kept) * (64 * R));
+    if ((threadIdx.x & 63u) == 0 && n_pairs) atomicAdd(&st.stats[ST_PAIR_PRETESTS_SHADOW], n_pairs);
     if ((threadIdx.x & 63u) == 0 && n_queued) atomicAdd(&st.stats[ST_QUEUED_SHADOW], static_cast<unsigned long long>(n_queued));
 }
 
@@ -1627,6 +1796,8 @@ struct rt_scene {
     std::vector<void*> allocations;
     // cone records for rays from the eye, rebuilt when the eye moves (one render at a time per scene)
     mutable float4* eye_records = nullptr;
+    mutable float4* eye_cluster_records = nullptr;
+    mutable float4* eye_top_records = nullptr;
     mutable float eye[3] = {0, 0, 0};
     mutable bool eye_valid = false;
 };
@@ -1706,13 +1877,19 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     hipStream_t stream = g_lib.stream;
     if (sc.n_tri && scene->eye_records) {
         if (!scene->eye_valid || std::memcmp(scene->eye, cam->eye, sizeof scene->eye) != 0) {
-            hipLaunchKernelGGL(k_prep_cone, dim3(ceil_div(sc.n_tri, BLOCK)), dim3(BLOCK), 0, stream, sc.tri, sc.n_tri,
+            hipLaunchKernelGGL(k_prep_cone, dim3(ceil_div(sc.n_tri, BLOCK)), dim3(BLOCK), 0, stream, sc.tri, sc.k_of, sc.n_tri,
                                cam->eye[0], cam->eye[1], cam->eye[2], sc.origin_bound, 0, scene->eye_records);
+            hipLaunchKernelGGL(k_prep_cluster_cone, dim3(ceil_div(sc.n_clusters, BLOCK)), dim3(BLOCK), 0, stream,
+                               static_cast<const float4*>(scene->eye_records), sc.n_tri, sc.n_clusters, scene->eye_cluster_records);
+            hipLaunchKernelGGL(k_prep_cluster_cone, dim3(ceil_div(sc.n_tops, BLOCK)), dim3(BLOCK), 0, stream,
+                               static_cast<const float4*>(scene->eye_cluster_records), sc.n_clusters, sc.n_tops, scene->eye_top_records);
             HIP_TRY(hipGetLastError());
             std::memcpy(scene->eye, cam->eye, sizeof scene->eye);
             scene->eye_valid = true;
         }
         sc.cone_eye = scene->eye_records;
+        sc.cl_eye = scene->eye_cluster_records;
+        sc.top_eye = scene->eye_top_records;
     }
     Frame f;
     std::memcpy(f.eye, cam->eye, sizeof f.eye);
@@ -1825,6 +2002,59 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     return 0;
 }
 
+// Cluster order of the triangles: the scan indices in the leaf order of a kd tree over their
+// centroids, degenerate and non-finite triangles last.  A range of more than CLUSTER*CLUSTER
+// triangles is split at a multiple of CLUSTER*CLUSTER near its middle along its longest axis,
+// a smaller one at a multiple of CLUSTER, so that every aligned group of CLUSTER positions is one
+// leaf (a compact patch) and every aligned group of CLUSTER clusters one subtree.
+// Only the pre-test records are stored in this order; it decides which triangles share a bounding
+// record and nothing else, so any permutation gives the same image.
+std::vector<uint32_t> cluster_order(const float* tri8, uint32_t nb) {
+    const uint32_t n = 8u * nb;
+    std::vector<float> centroid(static_cast<size_t>(n) * 3);
+    std::vector<uint32_t> order, rejects;
+    order.reserve(n);
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t j = k / nb, i = k % nb;
+        const float* p = tri8 + static_cast<size_t>(i) * 72 + j;
+        const double a[3] = {p[0], p[8], p[16]}, ab[3] = {p[24], p[32], p[40]}, ac[3] = {p[48], p[56], p[64]};
+        const double nx = ab[1] * ac[2] - ab[2] * ac[1], ny = ab[2] * ac[0] - ab[0] * ac[2], nz = ab[0] * ac[1] - ab[1] * ac[0];
+        const double c[3] = {a[0] + (ab[0] + ac[0]) / 3.0, a[1] + (ab[1] + ac[1]) / 3.0, a[2] + (ab[2] + ac[2]) / 3.0};
+        const double nn = nx * nx + ny * ny + nz * nz;
+        const bool good = std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(nn) && nn > 0.0;
+        for (int q = 0; q < 3; ++q) centroid[static_cast<size_t>(k) * 3 + q] = good ? static_cast<float>(c[q]) : 0.0f;
+        (good ? order : rejects).push_back(k);
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> todo;   // [begin, end) ranges of `order` still to split
+    todo.push_back({0u, static_cast<uint32_t>(order.size())});
+    while (!todo.empty()) {
+        const auto [begin, end] = todo.back();
+        todo.pop_back();
+        const uint32_t count = end - begin;
+        if (count <= CLUSTER) continue;
+        const uint32_t align = count > CLUSTER * CLUSTER ? CLUSTER * CLUSTER : CLUSTER;
+        uint32_t left = ((count / 2 + align / 2) / align) * align;
+        if (left == 0) left = align;
+        if (left >= count) left = count / 2;
+        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (uint32_t i = begin; i < end; ++i)
+            for (int q = 0; q < 3; ++q) {
+                const float v = centroid[static_cast<size_t>(order[i]) * 3 + q];
+                lo[q] = v < lo[q] ? v : lo[q]; hi[q] = v > hi[q] ? v : hi[q];
+            }
+        int axis = 0;
+        for (int q = 1; q < 3; ++q) if (hi[q] - lo[q] > hi[axis] - lo[axis]) axis = q;
+        std::nth_element(order.begin() + begin, order.begin() + begin + left, order.begin() + end, [&](uint32_t x, uint32_t y) {
+            const float cx = centroid[static_cast<size_t>(x) * 3 + axis], cy = centroid[static_cast<size_t>(y) * 3 + axis];
+            return cx < cy || (cx == cy && x < y);
+        });
+        todo.push_back({begin + left, end});
+        todo.push_back({begin, begin + left});
+    }
+    order.insert(order.end(), rejects.begin(), rejects.end());
+    return order;
+}
+
 template <typename T>
 int upload(rt_scene* s, const T* host, size_t count, T** dev) {
     *dev = nullptr;
@@ -1878,6 +2108,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     if (desc->n_triangle8 > (1u << 26) || desc->n_sphere8 > (1u << 26) || desc->n_ellipsoid8 > (1u << 26)) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^29 primitives of one kind");
     if (desc->n_triangles > desc->n_triangle8 * 8 || desc->n_spheres > desc->n_sphere8 * 8 || desc->n_ellipsoids > desc->n_ellipsoid8 * 8) return rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: more materials than primitive slots");
     if (desc->n_point_lights > 4096) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 4096 point lights");
+    if (desc->n_triangle8 > (1u << 21)) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^24 triangle slots");
     rt_scene* s = new rt_scene();
     auto fail = [&](int rc) { rt_scene_destroy(s); return rc; };
     DevScene& d = s->dev;
@@ -1908,11 +2139,31 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &tri))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &trif))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri), &s->eye_records))) return fail(rc);
-    float4 *cone_light, *sphere_any;
+    d.n_clusters = ceil_div(d.n_tri, CLUSTER);
+    d.n_tops = ceil_div(d.n_clusters, CLUSTER);
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_clusters), &s->eye_cluster_records))) return fail(rc);
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tops), &s->eye_top_records))) return fail(rc);
+    float4 *cone_light, *sphere_any, *cl_light, *cl_sphere, *top_light, *top_sphere;
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tops) * desc->n_point_lights, &top_light))) return fail(rc);
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tops), &top_sphere))) return fail(rc);
+    d.top_light = top_light;
+    d.top_sphere = top_sphere;
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * desc->n_point_lights, &cone_light))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri), &sphere_any))) return fail(rc);
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_clusters) * desc->n_point_lights, &cl_light))) return fail(rc);
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_clusters), &cl_sphere))) return fail(rc);
     d.cone_light = cone_light;
     d.sphere_any = sphere_any;
+    d.cl_light = cl_light;
+    d.cl_sphere = cl_sphere;
+    uint32_t* k_of = nullptr;
+    std::vector<uint32_t> order;   // stays alive until the stream has been synchronised below
+    if (d.n_tri) {
+        if (!desc->triangle8s) return fail(rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: triangle8s is null"));
+        order = cluster_order(desc->triangle8s, d.tri_nb);
+        if ((rc = upload(s, order.data(), order.size(), &k_of))) return fail(rc);
+    }
+    d.k_of = k_of;
     {
         float b = 0.0f;
         for (int i = 0; i < 6; ++i) b = std::fmax(b, std::fabs(desc->bounding_box[i]));
@@ -1922,11 +2173,21 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * 6, &ell))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * desc->n_point_lights, &ell_light))) return fail(rc);
     if (d.n_tri) hipLaunchKernelGGL(k_prep_triangles, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, raw_tri, d.tri_nb, tri, trif);
-    if (d.n_tri) hipLaunchKernelGGL(k_prep_sphere, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, tri, d.n_tri, d.origin_bound, sphere_any);
+    if (d.n_tri) {
+        hipLaunchKernelGGL(k_prep_sphere, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, tri, d.k_of, d.n_tri, d.origin_bound, sphere_any);
+        hipLaunchKernelGGL(k_prep_cluster_sphere, dim3(ceil_div(d.n_clusters, BLOCK)), dim3(BLOCK), 0, stream,
+                           static_cast<const float4*>(sphere_any), d.n_tri, d.n_clusters, d.origin_bound, cl_sphere);
+        hipLaunchKernelGGL(k_prep_cluster_sphere, dim3(ceil_div(d.n_tops, BLOCK)), dim3(BLOCK), 0, stream,
+                           static_cast<const float4*>(cl_sphere), d.n_clusters, d.n_tops, d.origin_bound, top_sphere);
+    }
     for (uint64_t l = 0; d.n_tri && l < desc->n_point_lights; ++l) {
         const float* L = desc->point_light_sources + l * 6;
-        hipLaunchKernelGGL(k_prep_cone, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, tri, d.n_tri, L[0], L[1], L[2], d.origin_bound, 1,
+        hipLaunchKernelGGL(k_prep_cone, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, tri, d.k_of, d.n_tri, L[0], L[1], L[2], d.origin_bound, 1,
                            cone_light + static_cast<size_t>(l) * d.n_tri);
+        hipLaunchKernelGGL(k_prep_cluster_cone, dim3(ceil_div(d.n_clusters, BLOCK)), dim3(BLOCK), 0, stream,
+                           static_cast<const float4*>(cone_light + static_cast<size_t>(l) * d.n_tri), d.n_tri, d.n_clusters, cl_light + static_cast<size_t>(l) * d.n_clusters);
+        hipLaunchKernelGGL(k_prep_cluster_cone, dim3(ceil_div(d.n_tops, BLOCK)), dim3(BLOCK), 0, stream,
+                           static_cast<const float4*>(cl_light + static_cast<size_t>(l) * d.n_clusters), d.n_clusters, d.n_tops, top_light + static_cast<size_t>(l) * d.n_tops);
     }
     if (d.n_sph) hipLaunchKernelGGL(k_prep_spheres, dim3(ceil_div(d.n_sph, BLOCK)), dim3(BLOCK), 0, stream, raw_sph, d.sph_nb, sph);
     if (d.n_ell) hipLaunchKernelGGL(k_prep_ellipsoids, dim3(ceil_div(d.n_ell, BLOCK)), dim3(BLOCK), 0, stream, raw_inv, raw_fwd, d.ell_nb, ell);
