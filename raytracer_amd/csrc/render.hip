@@ -69,23 +69,27 @@ constexpr uint32_t SAMPLES_PER_TILE = RT_TILE * RT_TILE * RT_SAMPLES_PER_PIXEL; 
 // keeps in lane j = k / nb of batch i = k % nb (original index 8*i + j).  Walking k upward
 // with a strict `<` then yields the reference's winner among equal distances, which is the
 // smallest (distance, lane, batch), not the smallest index (ray_tracing.cpp:489-516).
+// Bounding records of one primitive kind (triangles or ellipsoids), 1 x float4 each, for the
+// conservative pre-tests of the scans.  Three kinds of record: "eye" = cone of directions from the
+// camera eye (cone_keeps), "light" = the same from each point light, "sphere" = bounding sphere for
+// rays with their own origin (sphere_keeps).  Three levels: leaves (one per primitive), clusters
+// (CLUSTER consecutive leaves) and top nodes (CLUSTER consecutive clusters); a cluster or top record
+// contains the records of everything below it.  Leaves are stored in CLUSTER ORDER: position s
+// holds the primitive with scan index k_of[s], and consecutive positions are neighbours in space
+// (leaf order of a kd tree, built by the host at scene creation).
+struct Hierarchy {
+    const uint32_t* k_of;
+    const float4 *leaf_eye, *leaf_light, *leaf_sphere;   // leaf_light: [point light][position]
+    const float4 *cl_eye, *cl_light, *cl_sphere;
+    const float4 *top_eye, *top_light, *top_sphere;
+    uint32_t n, n_clusters, n_tops;
+};
+
 struct DevScene {
     const float4* tri;   // 4 x float4 per triangle: (a, n.x) (a_to_b, n.y) (a_to_c, n.z) (n.n, 0, 0, 0)
     const float4* trif;  // pre-test records, 4 x float4 per triangle, see pretest_stage1
-    // Pre-test records, 1 x float4 per triangle, in CLUSTER order: position s holds the triangle with scan index
-    // k_of[s]; consecutive positions are neighbours in space (sorted along a Z curve by the host at scene creation),
-    // and every CLUSTER consecutive positions have one record of the same kind that bounds them all.
-    const uint32_t* k_of;
-    const float4* cone_eye;     // cone records for rays from the camera eye, see cone_keeps
-    const float4* cone_light;   // [point light][position] cone records for shadow rays toward that light
-    const float4* sphere_any;   // bounding-sphere records for rays with their own origin, see sphere_keeps
-    const float4* cl_eye;       // [cluster] cone that contains the cones of its members
-    const float4* cl_light;     // [point light][cluster]
-    const float4* cl_sphere;    // [cluster] sphere that contains the spheres of its members
-    const float4* top_eye;      // [top node] the same one level up: a top node bounds CLUSTER consecutive clusters
-    const float4* top_light;    // [point light][top node]
-    const float4* top_sphere;
-    uint32_t n_clusters, n_tops;
+    Hierarchy th;        // bounding records of the triangles, see Hierarchy
+    Hierarchy eh;        // bounding records of the ellipsoids
     const float4* sph;   // (centre, radius)
     const float4* ell;   // 6 x float4: rows of the inverse transform, rows of the transform
     const float4* ell_light;  // [point light][ellipsoid]: inverse transform applied to the light position
@@ -119,6 +123,7 @@ struct State {
     float *cr, *cg, *cb;                  // accumulated colour
     float *px, *py, *pz, *nx, *ny, *nz;   // hit point and unit normal of the current bounce
     unsigned long long* key;              // closest triangle of the current bounce, see pack_hit
+    unsigned long long* key_ell;          // closest ellipsoid of the current bounce, same format
     uint32_t* hit_id;                     // RT_ID_MAKE(kind, original index) of the current bounce
     uint32_t* blocked;                    // bit l: light l of the current group is blocked
     uint32_t* list[2];                    // compacted slots of live rays, ping-pong
@@ -731,6 +736,122 @@ __global__ void __launch_bounds__(BLOCK) k_prep_ellipsoids(const float* __restri
     }
 }
 
+// ---- bounding records of the ellipsoids (all in double) ----
+// The full test (hit_ellipsoid / ellipsoid_blocks) maps the ray with the inverse transform
+// (rows i0..i2: linear part Ainv, translation t) and tests the unit sphere, so the solid it
+// tests is { x : |Ainv x + t| <= 1 }: centre c = -B t with B = Ainv^-1, and every point of it
+// within sigma_max(B) of c.  In binary32 the test also accepts rays that miss by a little:
+// with o2 the mapped origin (|o2| <= D2 = sigma_max(Ainv) * D, D = largest distance of an origin
+// from c), perp2 = o2.o2 - mid^2 carries up to 8 eps D2^2 of rounding, the mapped origin is off
+// by e_o <= 4 eps (3 sigma_max(Ainv) |o|_inf + |t|_inf) per component and the mapped direction by
+// an angle <= 4 sqrt(3) eps kappa (kappa = condition number).  A ray the full test accepts therefore
+// passes, in ellipsoid space, within rho = sqrt(1 + 16 eps D2^2) + 2 (sqrt(3) e_o + 4 sqrt(3) eps kappa D2)
+// of the origin (every noise term doubled), and in world space within sigma_max(B) * rho of c.
+struct EllBound { double c[3]; double r_geom, s_inv, kappa, t_max; bool ok; };
+__device__ double sym3_max_eig(double a00, double a01, double a02, double a11, double a12, double a22) {
+    const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+    const double q = (a00 + a11 + a22) / 3.0;
+    const double p2 = (a00 - q) * (a00 - q) + (a11 - q) * (a11 - q) + (a22 - q) * (a22 - q) + 2.0 * p1;
+    const double pp = sqrt(p2 / 6.0);
+    if (!(pp > 1.0e-300)) return q;
+    const double b00 = (a00 - q) / pp, b11 = (a11 - q) / pp, b22 = (a22 - q) / pp, b01 = a01 / pp, b02 = a02 / pp, b12 = a12 / pp;
+    const double det = b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02);
+    const double r = fmax(-1.0, fmin(1.0, det / 2.0));
+    return (q + 2.0 * pp * cos(acos(r) / 3.0)) * (1.0 + 1.0e-9) + 1.0e-300;
+}
+__device__ EllBound ell_bound(float4 i0, float4 i1, float4 i2) {
+    EllBound b;
+    const double A[3][3] = {{i0.x, i0.y, i0.z}, {i1.x, i1.y, i1.z}, {i2.x, i2.y, i2.z}};
+    const double t[3] = {i0.w, i1.w, i2.w};
+    const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) + A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+    b.ok = isfinite(det) && det != 0.0 && isfinite(t[0]) && isfinite(t[1]) && isfinite(t[2]);
+    b.c[0] = b.c[1] = b.c[2] = 0.0; b.r_geom = b.s_inv = b.kappa = b.t_max = 0.0;
+    if (!b.ok) return b;
+    double B[3][3];   // inverse of A
+    B[0][0] = (A[1][1] * A[2][2] - A[1][2] * A[2][1]) / det; B[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det; B[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det;
+    B[1][0] = (A[1][2] * A[2][0] - A[1][0] * A[2][2]) / det; B[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det; B[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det;
+    B[2][0] = (A[1][0] * A[2][1] - A[1][1] * A[2][0]) / det; B[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det; B[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
+    for (int r = 0; r < 3; ++r) b.c[r] = -(B[r][0] * t[0] + B[r][1] * t[1] + B[r][2] * t[2]);
+    auto gram_max = [](const double M[3][3]) {   // largest eigenvalue of M^T M
+        double g[3][3];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g[r][c] = M[0][r] * M[0][c] + M[1][r] * M[1][c] + M[2][r] * M[2][c];
+        return sym3_max_eig(g[0][0], g[0][1], g[0][2], g[1][1], g[1][2], g[2][2]);
+    };
+    b.r_geom = sqrt(gram_max(B));
+    b.s_inv = sqrt(gram_max(A));
+    b.kappa = b.r_geom * b.s_inv;
+    b.t_max = fmax(fabs(t[0]), fmax(fabs(t[1]), fabs(t[2])));
+    b.ok = isfinite(b.r_geom) && isfinite(b.s_inv) && isfinite(b.c[0]) && isfinite(b.c[1]) && isfinite(b.c[2]) && b.r_geom > 0.0;
+    return b;
+}
+// world-space radius around b.c that a ray the full test accepts stays within; D, o_max as above.  Infinite = no bound.
+__device__ double ell_reach(const EllBound& b, double D, double o_max) {
+    const double eps = 5.9604644775390625e-8;   // 2^-24
+    const double D2 = b.s_inv * D;
+    const double e_o = 4.0 * eps * (3.0 * b.s_inv * o_max + b.t_max);
+    const double rho = sqrt(1.0 + 16.0 * eps * D2 * D2) + 2.0 * (1.7320508075688772 * e_o + 4.0 * 1.7320508075688772 * eps * b.kappa * D2);
+    if (!(rho < 8.0)) return INFINITY;
+    return b.r_geom * rho * (1.0 + 1.0e-6);
+}
+// sphere records (sphere_keeps) of the ellipsoids, in cluster order
+__global__ void __launch_bounds__(BLOCK) k_prep_ell_sphere(const float4* __restrict__ ell, const uint32_t* __restrict__ k_of, uint32_t n, float origin_bound, float4* __restrict__ out) {
+    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
+    if (pos >= n) return;
+    const uint32_t k = k_of[pos];
+    const EllBound b = ell_bound(ell[static_cast<size_t>(k) * 6], ell[static_cast<size_t>(k) * 6 + 1], ell[static_cast<size_t>(k) * 6 + 2]);
+    float4 rec = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());   // keeps every ray
+    if (b.ok) {
+        const double eps = 5.9604644775390625e-8;
+        const double B = origin_bound;
+        const double c_len = sqrt(b.c[0] * b.c[0] + b.c[1] * b.c[1] + b.c[2] * b.c[2]);
+        const double c_max = fmax(fabs(b.c[0]), fmax(fabs(b.c[1]), fabs(b.c[2])));
+        const double D = 1.7320508075688772 * B + c_len;
+        const double r = ell_reach(b, D, B);
+        // as in k_prep_sphere: the pre-test's re-normalised direction, the centre rounded to binary32, m = o x d and c x d - m
+        const double T = 2.0 * (D + r);
+        const double r_tot = (r + 2.0 * (3.0 * eps * T + 2.0 * eps * c_max)) * (1.0 + 6.0 * eps) + 2.0 * 13.0 * eps * (c_max + B);
+        const double r2 = r_tot * r_tot * (1.0 + 1.0e-6);
+        if (r2 < 1.0e30) rec = make_float4(static_cast<float>(b.c[0]), static_cast<float>(b.c[1]), static_cast<float>(b.c[2]), nextafterf(static_cast<float>(r2), __builtin_inff()));
+    }
+    out[pos] = rec;
+}
+// cone records (cone_keeps) of the ellipsoids for rays through X, as k_prep_cone does for triangles:
+// reversed = 0: X is the eye and every ray starts there; reversed = 1: X is a point light, the
+// rays start within origin_bound of 0 and point at X up to the rounding of their direction.
+__global__ void __launch_bounds__(BLOCK) k_prep_ell_cone(const float4* __restrict__ ell, const uint32_t* __restrict__ k_of, uint32_t n, float x, float y, float z,
+                                                         float origin_bound, int reversed, float4* __restrict__ out) {
+    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
+    if (pos >= n) return;
+    const uint32_t k = k_of[pos];
+    const EllBound b = ell_bound(ell[static_cast<size_t>(k) * 6], ell[static_cast<size_t>(k) * 6 + 1], ell[static_cast<size_t>(k) * 6 + 2]);
+    float4 rec = make_float4(0.0f, 0.0f, 0.0f, -2.0f);   // keeps every ray
+    if (b.ok) {
+        const double eps = 5.9604644775390625e-8;
+        const double X[3] = {x, y, z};
+        const double to_c[3] = {b.c[0] - X[0], b.c[1] - X[1], b.c[2] - X[2]};
+        const double dist = sqrt(to_c[0] * to_c[0] + to_c[1] * to_c[1] + to_c[2] * to_c[2]);
+        const double x_max = fmax(fabs(X[0]), fmax(fabs(X[1]), fabs(X[2])));
+        const double c_len = sqrt(b.c[0] * b.c[0] + b.c[1] * b.c[1] + b.c[2] * b.c[2]);
+        const double D = reversed ? 1.7320508075688772 * origin_bound + c_len : dist;
+        const double r = ell_reach(b, D, reversed ? static_cast<double>(origin_bound) : x_max);
+        // a shadow ray's direction is a rounded quotient: its line misses X by up to 8 eps of the origin's distance from X
+        const double T_x = 2.0 * (1.7320508075688772 * origin_bound + x_max * 1.7320508075688772);
+        const double delta = reversed ? 2.0 * 8.0 * eps * T_x : 0.0;
+        const double reach = r + delta;
+        if (reach < 1.0e30 && dist > 1.01 * reach + 1.0e-30) {
+            const double theta = asin(reach / dist) + 1.0e-6;
+            if (theta < 1.5) {
+                const double cos_store = cos(theta) * (1.0 - 8.0 * eps) - 16.0 * eps;
+                const double sign = reversed ? -1.0 : 1.0;
+                rec = make_float4(static_cast<float>(sign * to_c[0] / dist), static_cast<float>(sign * to_c[1] / dist), static_cast<float>(sign * to_c[2] / dist),
+                                  nextafterf(static_cast<float>(cos_store), -2.0f));
+                if (!(rec.w > -1.0f && rec.w < 1.0f)) rec = make_float4(0.0f, 0.0f, 0.0f, -2.0f);
+            }
+        }
+    }
+    out[pos] = rec;
+}
+
 // inverse transform applied to each point light's position (ray_tracing.cpp:388), once per scene
 __global__ void __launch_bounds__(BLOCK) k_prep_ellipsoid_lights(const float4* __restrict__ ell, uint32_t n_ell, const float* __restrict__ point_lights,
                                                                  uint32_t n_point, float4* __restrict__ out) {
@@ -794,7 +915,7 @@ __global__ void __launch_bounds__(BLOCK) k_primary(Frame f, DevScene sc, State s
         st.dx[s] = d.x; st.dy[s] = d.y; st.dz[s] = d.z;
         st.wr[s] = 1.0f; st.wg[s] = 1.0f; st.wb[s] = 1.0f;
     }
-    if (live) st.key[s] = NO_HIT_KEY;
+    if (live) { st.key[s] = NO_HIT_KEY; st.key_ell[s] = NO_HIT_KEY; }
     if (st.primary_id) st.primary_id[s] = live ? RT_ID_MISS : RT_ID_CULLED;
     const unsigned long long live_mask = __ballot(live);    // list 0 is built from these by k_scan_flags + k_fill_list
     if ((threadIdx.x & 63u) == 0) st.flag_bits[blockIdx.x * 4u + (threadIdx.x >> 6)] = live_mask;
@@ -969,8 +1090,10 @@ DEV float pretests_then_full(const DevScene& sc, uint32_t k, V3 o, V3 d, uint32_
 // 2: cone pre-test for rays from the eye (bounce 0); 3: bounding-sphere pre-test for rays with their own origin.
 // In modes 2 and 3 a lane keeps only direction (and moment) of its R rays; pairs the pre-test
 // keeps are queued and drained through pretests_then_full.  Result: st.key[slot].
-template <int R, int MODE>
-__global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, uint32_t bounce) {
+template <int R, int MODE, int PRIM>
+__global__ void __launch_bounds__(BLOCK) k_closest_scan(DevScene sc, State st, uint32_t bounce) {
+    static_assert(MODE != 0 || PRIM == 0, "the full-test mode of this kernel is for triangles");
+    const Hierarchy& h = PRIM == 0 ? sc.th : sc.eh;
     constexpr int WORDS = 4;
     __shared__ float4 lds[MODE == 0 ? TILE_PRIMS * WORDS : 1];   // record tiles, full-test mode only
     constexpr uint32_t WAVE_LDS = 3 * QCAP + 64 * R;   // per wave: (ray, top node), (ray, cluster) and (ray, triangle) queues, slot table
@@ -981,7 +1104,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
     if (MODE == 0) {
         split = ScanSplit{blockIdx.x * (BLOCK * R), 0u, sc.n_tri, blockIdx.x * (BLOCK * R) < n_rays};
     } else {
-        split = scan_split(n_rays, BLOCK * R, sc.n_tops);
+        split = scan_split(n_rays, BLOCK * R, h.n_tops);
     }
     if (!split.active) return;
     const uint32_t base = split.ray_base;
@@ -1051,20 +1174,27 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
         packet = uniform_packet(make_packet<R>(d, MODE == 3 ? o : nullptr, valid));
     }
     const bool keep_all = MODE == 3 && __any(unsafe);
-    const float4* __restrict__ top_stream = MODE == 2 ? sc.top_eye : sc.top_sphere;
-    const float4* __restrict__ cluster_stream = MODE == 2 ? sc.cl_eye : sc.cl_sphere;
-    const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_eye : sc.sphere_any;
+    const float4* __restrict__ top_stream = MODE == 2 ? h.top_eye : h.top_sphere;
+    const float4* __restrict__ cluster_stream = MODE == 2 ? h.cl_eye : h.cl_sphere;
+    const float4* __restrict__ leaf_stream = MODE == 2 ? h.leaf_eye : h.leaf_sphere;
 
     // (ray, triangle) pairs: two-stage pre-test and full test, one pair per lane
     auto drain2 = [&]() {
         wave_sync();
         for (uint32_t i = lane; i < q2_count; i += 64) {
             const uint32_t e = q2[i];
-            const uint32_t s = wave_slots[e >> 24], k = sc.k_of[e & NODE_MASK];
+            const uint32_t s = wave_slots[e >> 24], k = h.k_of[e & NODE_MASK];
             const V3 o{st.ox[s], st.oy[s], st.oz[s]};
             const V3 dd{st.dx[s], st.dy[s], st.dz[s]};
-            const float t = pretests_then_full(sc, k, o, dd, n_full);
-            if (t < FLT_MAX) atomicMin(&st.key[s], pack_hit(t, k));
+            if (PRIM == 0) {
+                const float t = pretests_then_full(sc, k, o, dd, n_full);
+                if (t < FLT_MAX) atomicMin(&st.key[s], pack_hit(t, k));
+            } else {
+                const float4* __restrict__ rec = sc.ell + static_cast<size_t>(k) * 6;
+                const float t = hit_ellipsoid(o, dd, rec[0], rec[1], rec[2], rec[3], rec[4], rec[5]);
+                n_full++;
+                if (t < FLT_MAX) atomicMin(&st.key_ell[s], pack_hit(t, k));
+            }
         }
         wave_sync();
         n_queued += q2_count;
@@ -1105,8 +1235,8 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
         wave_sync();
         in_count = 0;
     };
-    auto drain1 = [&]() { walk(q1, q1_count, tri_stream, sc.n_tri, q2, q2_count, drain2); };
-    auto drain0 = [&]() { walk(q0, q0_count, cluster_stream, sc.n_clusters, q1, q1_count, drain1); };
+    auto drain1 = [&]() { walk(q1, q1_count, leaf_stream, h.n, q2, q2_count, drain2); };
+    auto drain0 = [&]() { walk(q0, q0_count, cluster_stream, h.n_clusters, q1, q1_count, drain1); };
 
     wave_sync();
     for (uint32_t c0 = split.first_prim; c0 < split.end_prim; c0 += 64) {
@@ -1129,7 +1259,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri(DevScene sc, State st, ui
     drain0();
     drain1();
     drain2();
-    block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
+    if (PRIM == 0) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
     if (lane == 0 && n_pairs) atomicAdd(&st.stats[ST_PAIR_PRETESTS], n_pairs);
     if (lane == 0 && n_queued) atomicAdd(&st.stats[ST_QUEUED], static_cast<unsigned long long>(n_queued));
 }
@@ -1196,10 +1326,8 @@ __global__ void __launch_bounds__(BLOCK) k_closest_ell(DevScene sc, State st, ui
             }
         }
     }
-    float* out_t = closest_t_slot(st, 2);
-    uint32_t* out_k = closest_k_slot(st, 2);
 #pragma unroll
-    for (int r = 0; r < R; ++r) if (valid[r]) { out_t[slot[r]] = best_t[r]; out_k[slot[r]] = best_k[r]; }
+    for (int r = 0; r < R; ++r) if (valid[r]) st.key_ell[slot[r]] = best_k[r] == 0xFFFFFFFFu ? NO_HIT_KEY : pack_hit(best_t[r], best_k[r]);
 }
 
 // k_hit: one ray per thread.  Kind choice (ray_tracing.cpp:610-680), hit point, normal,
@@ -1220,7 +1348,11 @@ __global__ void __launch_bounds__(BLOCK) k_hit(DevScene sc, State st, uint32_t b
         if (k_kind[0] != 0xFFFFFFFFu) t_kind[0] = __uint_as_float(static_cast<uint32_t>(key >> 32));
     }
     if (sc.n_sph) { t_kind[1] = closest_t_slot(st, 1)[s]; k_kind[1] = closest_k_slot(st, 1)[s]; }
-    if (sc.n_ell) { t_kind[2] = closest_t_slot(st, 2)[s]; k_kind[2] = closest_k_slot(st, 2)[s]; }
+    if (sc.n_ell) {
+        const unsigned long long key = st.key_ell[s];
+        k_kind[2] = static_cast<uint32_t>(key & 0xFFFFFFFFull);
+        if (k_kind[2] != 0xFFFFFFFFu) t_kind[2] = __uint_as_float(static_cast<uint32_t>(key >> 32));
+    }
     const float tri_t = t_kind[0], sph_t = t_kind[1], ell_t = t_kind[2];
     const bool any = (k_kind[0] != 0xFFFFFFFFu) | (k_kind[1] != 0xFFFFFFFFu) | (k_kind[2] != 0xFFFFFFFFu);
     // ray_tracing.cpp:616, :637, :655
@@ -1275,6 +1407,7 @@ __global__ void __launch_bounds__(BLOCK) k_hit(DevScene sc, State st, uint32_t b
         st.hit_id[s] = id;
         st.blocked[s] = 0u;
         st.key[s] = NO_HIT_KEY;      // for the next bounce's triangle scan
+        st.key_ell[s] = NO_HIT_KEY;
         if (bounce == 0 && st.primary_id) st.primary_id[s] = id;
     }
     const unsigned long long hit_mask = __ballot(hit);      // the next list is built from these by k_scan_flags + k_fill_list
@@ -1361,10 +1494,12 @@ DEV ShadowRay make_shadow_ray(const State& st, uint32_t slot, bool point, V3 lv)
 
 // MODE 0: full test only; 2: cone pre-test (point lights only: lights first_light.. are point
 // lights, their cone records start at sc.cone_light); 3: bounding-sphere pre-test for rays with their own
-// origin (any light).  Queue and drain as in k_closest_tri; a drained pair that blocks sets the
+// origin (any light).  Queues as in k_closest_scan; a drained pair that blocks sets the
 // owner's bit in LDS, which the owner picks up after the drain.
-template <int R, int MODE>
-__global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
+template <int R, int MODE, int PRIM>
+__global__ void __launch_bounds__(BLOCK) k_shadow_scan(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
+    static_assert(MODE != 0 || PRIM == 0, "the full-test mode of this kernel is for triangles");
+    const Hierarchy& h = PRIM == 0 ? sc.th : sc.eh;
     constexpr int WORDS = 4;
     __shared__ float4 lds[MODE == 0 ? TILE_PRIMS * WORDS : 1];   // record tiles, full-test mode only
     constexpr uint32_t WAVE_LDS = 3 * QCAP + 64 * R;   // per wave: (ray, top node), (ray, cluster) and (ray, triangle) queues, slot table
@@ -1375,7 +1510,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
     if (MODE == 0) {
         split = ScanSplit{blockIdx.x * (BLOCK * R), 0u, sc.n_tri, blockIdx.x * (BLOCK * R) < n_rays};
     } else {
-        split = scan_split(n_rays, BLOCK * R, sc.n_tops);
+        split = scan_split(n_rays, BLOCK * R, h.n_tops);
     }
     if (!split.active) return;
     const uint32_t base = split.ray_base;
@@ -1386,7 +1521,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
     const bool point = L[0] != 0.0f;
     const V3 lv{L[1], L[2], L[3]};
 
-    // a wave owns 64*R consecutive rays of the list (see k_closest_tri)
+    // a wave owns 64*R consecutive rays of the list (see k_closest_scan)
     uint32_t slot[R];
     bool valid[R], blocked[R];
     V3 d[R], moment[R];
@@ -1427,9 +1562,9 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
     uint32_t q0_count = 0, q1_count = 0, q2_count = 0, n_full = 0, n_queued = 0;
     unsigned long long n_pairs = 0;
     const size_t light_index = MODE == 2 ? light - sc.has_directional : 0u;
-    const float4* __restrict__ top_stream = MODE == 2 ? sc.top_light + light_index * sc.n_tops : sc.top_sphere;
-    const float4* __restrict__ cluster_stream = MODE == 2 ? sc.cl_light + light_index * sc.n_clusters : sc.cl_sphere;
-    const float4* __restrict__ member_stream = MODE == 2 ? sc.cone_light + static_cast<size_t>(light - sc.has_directional) * sc.n_tri : sc.sphere_any;
+    const float4* __restrict__ top_stream = MODE == 2 ? h.top_light + light_index * h.n_tops : h.top_sphere;
+    const float4* __restrict__ cluster_stream = MODE == 2 ? h.cl_light + light_index * h.n_clusters : h.cl_sphere;
+    const float4* __restrict__ member_stream = MODE == 2 ? h.leaf_light + light_index * h.n : h.leaf_sphere;
     // blocked bits of the wave's rays live in lds_blocked[thread that holds the ray], bit r; ray = r*64 + lane
     auto ray_blocked = [&](uint32_t ray) {
         return ((__hip_atomic_load(&lds_blocked[wave * 64u + (ray & 63u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> (ray >> 6)) & 1u) != 0u;
@@ -1439,10 +1574,18 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
         wave_sync();
         for (uint32_t i = lane; i < q2_count; i += 64) {
             const uint32_t e = q2[i];
-            const uint32_t ray = e >> 24, k = sc.k_of[e & NODE_MASK];
+            const uint32_t ray = e >> 24, k = h.k_of[e & NODE_MASK];
             const ShadowRay s = make_shadow_ray(st, wave_slots[ray], point, lv);
-            const float t = pretests_then_full(sc, k, s.o, s.d, n_full);
-            if (t < s.limit) atomicOr(&lds_blocked[wave * 64u + (ray & 63u)], 1u << (ray >> 6));
+            bool blocks;
+            if (PRIM == 0) {
+                blocks = pretests_then_full(sc, k, s.o, s.d, n_full) < s.limit;
+            } else {
+                const float4* __restrict__ rec = sc.ell + static_cast<size_t>(k) * 6;
+                const V3 l2 = point ? xyz(sc.ell_light[static_cast<size_t>(light - sc.has_directional) * sc.n_ell + k]) : V3{0.0f, 0.0f, 0.0f};
+                blocks = ellipsoid_blocks(s.o, s.d, rec[0], rec[1], rec[2], point, l2);
+                n_full++;
+            }
+            if (blocks) atomicOr(&lds_blocked[wave * 64u + (ray & 63u)], 1u << (ray >> 6));
         }
         wave_sync();
         n_queued += q2_count;
@@ -1485,13 +1628,12 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
         wave_sync();
         in_count = 0;
     };
-    auto drain1 = [&]() { walk(q1, q1_count, member_stream, sc.n_tri, q2, q2_count, drain2); };
-    auto drain0 = [&]() { walk(q0, q0_count, cluster_stream, sc.n_clusters, q1, q1_count, drain1); };
+    auto drain1 = [&]() { walk(q1, q1_count, member_stream, h.n, q2, q2_count, drain2); };
+    auto drain0 = [&]() { walk(q0, q0_count, cluster_stream, h.n_clusters, q1, q1_count, drain1); };
 
     unsigned long long wave_tests = 0;   // tests spent on still-undecided rays (wave-uniform)
     bool done = wave_done();
-    const float4* __restrict__ tri_stream = MODE == 2 ? sc.cone_light + static_cast<size_t>(light - sc.has_directional) * sc.n_tri
-                                                      : (MODE == 3 ? sc.sphere_any : sc.tri);
+    const float4* __restrict__ tri_stream = sc.tri;   // full-test mode
     if (MODE == 0) {
         for (uint32_t first = split.first_prim; first < split.end_prim; first += TILE_PRIMS) {
             const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), split.end_prim - first);
@@ -1527,7 +1669,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
         uint32_t live = live_rays(), steps = 0;
         for (uint32_t c0 = split.first_prim; c0 < split.end_prim && live != 0; c0 += 64) {
             const float4 mine = top_stream[min(c0 + lane, split.end_prim - 1u)];
-            wave_tests += static_cast<unsigned long long>(min(sc.n_tri, min(c0 + 64u, split.end_prim) * (CLUSTER * CLUSTER)) - c0 * (CLUSTER * CLUSTER)) * live;
+            wave_tests += static_cast<unsigned long long>(min(h.n, min(c0 + 64u, split.end_prim) * (CLUSTER * CLUSTER)) - c0 * (CLUSTER * CLUSTER)) * live;
             const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine) : packet_sphere_keeps(packet, mine);
             unsigned long long mask = __ballot((reach || keep_all) && c0 + lane < split.end_prim);
             while (mask) {
@@ -1549,8 +1691,8 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri(DevScene sc, State st, uin
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if (valid[r] && blocked[r]) atomicOr(&st.blocked[slot[r]], light_bit);
-    if ((threadIdx.x & 63u) == 0 && wave_tests) atomicAdd(&st.stats[ST_SHADOW_TESTS_TRI], wave_tests);
-    if (MODE != 0) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
+    if ((threadIdx.x & 63u) == 0 && wave_tests) atomicAdd(&st.stats[PRIM == 0 ? ST_SHADOW_TESTS_TRI : ST_SHADOW_TESTS_ELL], wave_tests);
+    if (MODE != 0 && PRIM == 0) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
     if ((threadIdx.x & 63u) == 0 && n_pairs) atomicAdd(&st.stats[ST_PAIR_PRETESTS_SHADOW], n_pairs);
     if ((threadIdx.x & 63u) == 0 && n_queued) atomicAdd(&st.stats[ST_QUEUED_SHADOW], static_cast<unsigned long long>(n_queued));
 }
@@ -1767,7 +1909,7 @@ constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;   // full-test, sphere and ellip
 // The pre-test scans execute so few instructions per test that the LDS broadcast reads of the
 // records (4 LDS cycles per float4 per wave) only stay hidden with several rays per lane.
 constexpr int R_CONE = RT_R_CONE, R_STRIP = RT_R_STRIP, R_SHADOW_CONE = RT_R_SHADOW_CONE, R_SHADOW_STRIP = RT_R_SHADOW_STRIP;
-constexpr uint32_t DEFAULT_CHUNK_TILES = 8192;   // 33.5 M samples, 3.4 GB of ray state
+constexpr uint32_t DEFAULT_CHUNK_TILES = 8192;   // 33.5 M samples, 3.6 GB of ray state
 constexpr uint32_t MAX_BOUNCES = 62;
 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
@@ -1795,9 +1937,8 @@ struct rt_scene {
     DevScene dev;
     std::vector<void*> allocations;
     // cone records for rays from the eye, rebuilt when the eye moves (one render at a time per scene)
-    mutable float4* eye_records = nullptr;
-    mutable float4* eye_cluster_records = nullptr;
-    mutable float4* eye_top_records = nullptr;
+    struct EyeRecords { float4 *leaf = nullptr, *cl = nullptr, *top = nullptr; };
+    mutable EyeRecords eye_tri, eye_ell;
     mutable float eye[3] = {0, 0, 0};
     mutable bool eye_valid = false;
 };
@@ -1807,9 +1948,9 @@ namespace {
 int ensure_state(size_t samples) {
     if (g_lib.state_samples >= samples) return 0;
     if (g_lib.state_mem) { HIP_TRY(hipFree(g_lib.state_mem)); g_lib.state_mem = nullptr; g_lib.state_samples = 0; }
-    // 18 float arrays + hit_id + blocked + 2 lists + primary ids + 64-bit keys = 25 words per sample
+    // 18 float arrays + hit_id + blocked + 2 lists + primary ids + two 64-bit keys = 27 words per sample
     // + per 256 samples: 4 wave ballots and one offset (ordered compaction)
-    HIP_TRY(hipMalloc(&g_lib.state_mem, samples * 25 * sizeof(float) + samples / BLOCK * 40));
+    HIP_TRY(hipMalloc(&g_lib.state_mem, samples * 27 * sizeof(float) + samples / BLOCK * 40));
     g_lib.state_samples = samples;
     return 0;
 }
@@ -1825,7 +1966,8 @@ State make_state(size_t samples, bool want_ids) {
     st.hit_id = u; st.blocked = u + samples; st.list[0] = u + 2 * samples; st.list[1] = u + 3 * samples;
     st.primary_id = want_ids ? u + 4 * samples : nullptr;
     st.key = reinterpret_cast<unsigned long long*>(u + 5 * samples);   // 8-byte aligned: samples is a multiple of 4096
-    st.flag_bits = st.key + samples;                                   // 16-byte aligned likewise
+    st.key_ell = st.key + samples;
+    st.flag_bits = st.key_ell + samples;                               // 16-byte aligned likewise
     st.wg_offset = reinterpret_cast<uint32_t*>(st.flag_bits + samples / BLOCK * 4);
     st.counts = g_lib.counts;
     st.stats = g_lib.stats;
@@ -1875,22 +2017,28 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
 
     DevScene sc = scene->dev;
     hipStream_t stream = g_lib.stream;
-    if (sc.n_tri && scene->eye_records) {
-        if (!scene->eye_valid || std::memcmp(scene->eye, cam->eye, sizeof scene->eye) != 0) {
-            hipLaunchKernelGGL(k_prep_cone, dim3(ceil_div(sc.n_tri, BLOCK)), dim3(BLOCK), 0, stream, sc.tri, sc.k_of, sc.n_tri,
-                               cam->eye[0], cam->eye[1], cam->eye[2], sc.origin_bound, 0, scene->eye_records);
-            hipLaunchKernelGGL(k_prep_cluster_cone, dim3(ceil_div(sc.n_clusters, BLOCK)), dim3(BLOCK), 0, stream,
-                               static_cast<const float4*>(scene->eye_records), sc.n_tri, sc.n_clusters, scene->eye_cluster_records);
-            hipLaunchKernelGGL(k_prep_cluster_cone, dim3(ceil_div(sc.n_tops, BLOCK)), dim3(BLOCK), 0, stream,
-                               static_cast<const float4*>(scene->eye_cluster_records), sc.n_clusters, sc.n_tops, scene->eye_top_records);
-            HIP_TRY(hipGetLastError());
-            std::memcpy(scene->eye, cam->eye, sizeof scene->eye);
-            scene->eye_valid = true;
+    if (!scene->eye_valid || std::memcmp(scene->eye, cam->eye, sizeof scene->eye) != 0) {
+        // the records for rays from the eye depend on where the eye is
+        auto rebuild = [&](const Hierarchy& h, const rt_scene::EyeRecords& e) {
+            hipLaunchKernelGGL(k_prep_cluster_cone, dim3(ceil_div(h.n_clusters, BLOCK)), dim3(BLOCK), 0, stream, static_cast<const float4*>(e.leaf), h.n, h.n_clusters, e.cl);
+            hipLaunchKernelGGL(k_prep_cluster_cone, dim3(ceil_div(h.n_tops, BLOCK)), dim3(BLOCK), 0, stream, static_cast<const float4*>(e.cl), h.n_clusters, h.n_tops, e.top);
+        };
+        if (sc.n_tri) {
+            hipLaunchKernelGGL(k_prep_cone, dim3(ceil_div(sc.n_tri, BLOCK)), dim3(BLOCK), 0, stream, sc.tri, sc.th.k_of, sc.n_tri,
+                               cam->eye[0], cam->eye[1], cam->eye[2], sc.origin_bound, 0, scene->eye_tri.leaf);
+            rebuild(sc.th, scene->eye_tri);
         }
-        sc.cone_eye = scene->eye_records;
-        sc.cl_eye = scene->eye_cluster_records;
-        sc.top_eye = scene->eye_top_records;
+        if (sc.n_ell) {
+            hipLaunchKernelGGL(k_prep_ell_cone, dim3(ceil_div(sc.n_ell, BLOCK)), dim3(BLOCK), 0, stream, sc.ell, sc.eh.k_of, sc.n_ell,
+                               cam->eye[0], cam->eye[1], cam->eye[2], sc.origin_bound, 0, scene->eye_ell.leaf);
+            rebuild(sc.eh, scene->eye_ell);
+        }
+        HIP_TRY(hipGetLastError());
+        std::memcpy(scene->eye, cam->eye, sizeof scene->eye);
+        scene->eye_valid = true;
     }
+    sc.th.leaf_eye = scene->eye_tri.leaf; sc.th.cl_eye = scene->eye_tri.cl; sc.th.top_eye = scene->eye_tri.top;
+    sc.eh.leaf_eye = scene->eye_ell.leaf; sc.eh.cl_eye = scene->eye_ell.cl; sc.eh.top_eye = scene->eye_ell.top;
     Frame f;
     std::memcpy(f.eye, cam->eye, sizeof f.eye);
     std::memcpy(f.bi, cam->basis_i, sizeof f.bi);
@@ -1929,12 +2077,16 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         for (uint32_t b = 0; b < depth; ++b) {
             timed(timer, 0, [&] {
                 if (sc.n_tri) {
-                    if (!filter) hipLaunchKernelGGL((k_closest_tri<RAYS_PER_LANE, 0>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-                    else if (b == 0 && sc.cone_eye) hipLaunchKernelGGL((k_closest_tri<R_CONE, 2>), dim3(blocks_for(R_CONE)), dim3(BLOCK), 0, stream, sc, st, b);
-                    else hipLaunchKernelGGL((k_closest_tri<R_STRIP, 3>), dim3(blocks_for(R_STRIP)), dim3(BLOCK), 0, stream, sc, st, b);
+                    if (!filter) hipLaunchKernelGGL((k_closest_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+                    else if (b == 0) hipLaunchKernelGGL((k_closest_scan<R_CONE, 2, 0>), dim3(blocks_for(R_CONE)), dim3(BLOCK), 0, stream, sc, st, b);
+                    else hipLaunchKernelGGL((k_closest_scan<R_STRIP, 3, 0>), dim3(blocks_for(R_STRIP)), dim3(BLOCK), 0, stream, sc, st, b);
                 }
                 if (sc.n_sph) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-                if (sc.n_ell) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+                if (sc.n_ell) {
+                    if (!filter) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
+                    else if (b == 0) hipLaunchKernelGGL((k_closest_scan<R_CONE, 2, 1>), dim3(blocks_for(R_CONE)), dim3(BLOCK), 0, stream, sc, st, b);
+                    else hipLaunchKernelGGL((k_closest_scan<R_STRIP, 3, 1>), dim3(blocks_for(R_STRIP)), dim3(BLOCK), 0, stream, sc, st, b);
+                }
             });
             hipLaunchKernelGGL(k_hit, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, st, b);
             hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(st.counts + b), 0u, st.counts + b + 1,
@@ -1951,14 +2103,20 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                     const uint32_t n_pt = group - n_dir;
                     timed(timer, 1, [&] {
                         if (sc.n_tri) {
-                            if (!filter) hipLaunchKernelGGL((k_shadow_tri<RAYS_PER_LANE, 0>), dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
+                            if (!filter) hipLaunchKernelGGL((k_shadow_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
                             else {
-                                if (n_dir) hipLaunchKernelGGL((k_shadow_tri<R_SHADOW_STRIP, 3>), dim3(blocks_for(R_SHADOW_STRIP), 1), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
-                                if (n_pt) hipLaunchKernelGGL((k_shadow_tri<R_SHADOW_CONE, 2>), dim3(blocks_for(R_SHADOW_CONE), n_pt), dim3(BLOCK), 0, stream, sc, st, b, l0 + n_dir, l0);
+                                if (n_dir) hipLaunchKernelGGL((k_shadow_scan<R_SHADOW_STRIP, 3, 0>), dim3(blocks_for(R_SHADOW_STRIP), 1), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
+                                if (n_pt) hipLaunchKernelGGL((k_shadow_scan<R_SHADOW_CONE, 2, 0>), dim3(blocks_for(R_SHADOW_CONE), n_pt), dim3(BLOCK), 0, stream, sc, st, b, l0 + n_dir, l0);
                             }
                         }
                         if (sc.n_sph) hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
-                        if (sc.n_ell) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
+                        if (sc.n_ell) {
+                            if (!filter) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
+                            else {
+                                if (n_dir) hipLaunchKernelGGL((k_shadow_scan<R_SHADOW_STRIP, 3, 1>), dim3(blocks_for(R_SHADOW_STRIP), 1), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
+                                if (n_pt) hipLaunchKernelGGL((k_shadow_scan<R_SHADOW_CONE, 2, 1>), dim3(blocks_for(R_SHADOW_CONE), n_pt), dim3(BLOCK), 0, stream, sc, st, b, l0 + n_dir, l0);
+                            }
+                        }
                     });
                     hipLaunchKernelGGL(k_shade, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, st, b, l0, group, (l0 + group == sc.n_lights) ? 1u : 0u);
                 }
@@ -2009,22 +2167,11 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
 // leaf (a compact patch) and every aligned group of CLUSTER clusters one subtree.
 // Only the pre-test records are stored in this order; it decides which triangles share a bounding
 // record and nothing else, so any permutation gives the same image.
-std::vector<uint32_t> cluster_order(const float* tri8, uint32_t nb) {
-    const uint32_t n = 8u * nb;
-    std::vector<float> centroid(static_cast<size_t>(n) * 3);
+std::vector<uint32_t> cluster_order(const std::vector<float>& centroid, const std::vector<uint8_t>& good) {
+    const uint32_t n = static_cast<uint32_t>(good.size());
     std::vector<uint32_t> order, rejects;
     order.reserve(n);
-    for (uint32_t k = 0; k < n; ++k) {
-        const uint32_t j = k / nb, i = k % nb;
-        const float* p = tri8 + static_cast<size_t>(i) * 72 + j;
-        const double a[3] = {p[0], p[8], p[16]}, ab[3] = {p[24], p[32], p[40]}, ac[3] = {p[48], p[56], p[64]};
-        const double nx = ab[1] * ac[2] - ab[2] * ac[1], ny = ab[2] * ac[0] - ab[0] * ac[2], nz = ab[0] * ac[1] - ab[1] * ac[0];
-        const double c[3] = {a[0] + (ab[0] + ac[0]) / 3.0, a[1] + (ab[1] + ac[1]) / 3.0, a[2] + (ab[2] + ac[2]) / 3.0};
-        const double nn = nx * nx + ny * ny + nz * nz;
-        const bool good = std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(nn) && nn > 0.0;
-        for (int q = 0; q < 3; ++q) centroid[static_cast<size_t>(k) * 3 + q] = good ? static_cast<float>(c[q]) : 0.0f;
-        (good ? order : rejects).push_back(k);
-    }
+    for (uint32_t k = 0; k < n; ++k) (good[k] ? order : rejects).push_back(k);
     std::vector<std::pair<uint32_t, uint32_t>> todo;   // [begin, end) ranges of `order` still to split
     todo.push_back({0u, static_cast<uint32_t>(order.size())});
     while (!todo.empty()) {
@@ -2053,6 +2200,41 @@ std::vector<uint32_t> cluster_order(const float* tri8, uint32_t nb) {
     }
     order.insert(order.end(), rejects.begin(), rejects.end());
     return order;
+}
+
+// centroids of the triangles in scan order (k = lane * batches + batch), and which of them are proper triangles
+void triangle_centroids(const float* tri8, uint32_t nb, std::vector<float>& centroid, std::vector<uint8_t>& good) {
+    const uint32_t n = 8u * nb;
+    centroid.assign(static_cast<size_t>(n) * 3, 0.0f);
+    good.assign(n, 0);
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t j = k / nb, i = k % nb;
+        const float* p = tri8 + static_cast<size_t>(i) * 72 + j;
+        const double a[3] = {p[0], p[8], p[16]}, ab[3] = {p[24], p[32], p[40]}, ac[3] = {p[48], p[56], p[64]};
+        const double nx = ab[1] * ac[2] - ab[2] * ac[1], ny = ab[2] * ac[0] - ab[0] * ac[2], nz = ab[0] * ac[1] - ab[1] * ac[0];
+        const double c[3] = {a[0] + (ab[0] + ac[0]) / 3.0, a[1] + (ab[1] + ac[1]) / 3.0, a[2] + (ab[2] + ac[2]) / 3.0};
+        const double nn = nx * nx + ny * ny + nz * nz;
+        good[k] = std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(nn) && nn > 0.0;
+        if (good[k]) for (int q = 0; q < 3; ++q) centroid[static_cast<size_t>(k) * 3 + q] = static_cast<float>(c[q]);
+    }
+}
+// centres of the ellipsoids in scan order: the translation column of the forward transform (Mat3x4x8, ray_tracing.h:62-69)
+void ellipsoid_centroids(const float* fwd8, const float* inv8, uint32_t nb, std::vector<float>& centroid, std::vector<uint8_t>& good) {
+    const uint32_t n = 8u * nb;
+    centroid.assign(static_cast<size_t>(n) * 3, 0.0f);
+    good.assign(n, 0);
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t j = k / nb, i = k % nb;
+        const float* pf = fwd8 + static_cast<size_t>(i) * 96 + j;
+        const float* pi = inv8 + static_cast<size_t>(i) * 96 + j;
+        double c[3], scale = 0.0;
+        for (int row = 0; row < 3; ++row) {
+            c[row] = pf[(row * 4 + 3) * 8];
+            for (int col = 0; col < 3; ++col) scale += std::fabs(static_cast<double>(pi[(row * 4 + col) * 8]));
+        }
+        good[k] = std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(scale) && scale > 0.0;
+        if (good[k]) for (int q = 0; q < 3; ++q) centroid[static_cast<size_t>(k) * 3 + q] = static_cast<float>(c[q]);
+    }
 }
 
 template <typename T>
@@ -2108,7 +2290,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     if (desc->n_triangle8 > (1u << 26) || desc->n_sphere8 > (1u << 26) || desc->n_ellipsoid8 > (1u << 26)) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^29 primitives of one kind");
     if (desc->n_triangles > desc->n_triangle8 * 8 || desc->n_spheres > desc->n_sphere8 * 8 || desc->n_ellipsoids > desc->n_ellipsoid8 * 8) return rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: more materials than primitive slots");
     if (desc->n_point_lights > 4096) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 4096 point lights");
-    if (desc->n_triangle8 > (1u << 21)) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^24 triangle slots");
+    if (desc->n_triangle8 > (1u << 21) || desc->n_ellipsoid8 > (1u << 21)) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^24 triangle or ellipsoid slots");
     rt_scene* s = new rt_scene();
     auto fail = [&](int rc) { rt_scene_destroy(s); return rc; };
     DevScene& d = s->dev;
@@ -2138,62 +2320,70 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     float4 *tri, *trif, *sph, *ell, *ell_light;
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &tri))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &trif))) return fail(rc);
-    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri), &s->eye_records))) return fail(rc);
-    d.n_clusters = ceil_div(d.n_tri, CLUSTER);
-    d.n_tops = ceil_div(d.n_clusters, CLUSTER);
-    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_clusters), &s->eye_cluster_records))) return fail(rc);
-    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tops), &s->eye_top_records))) return fail(rc);
-    float4 *cone_light, *sphere_any, *cl_light, *cl_sphere, *top_light, *top_sphere;
-    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tops) * desc->n_point_lights, &top_light))) return fail(rc);
-    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tops), &top_sphere))) return fail(rc);
-    d.top_light = top_light;
-    d.top_sphere = top_sphere;
-    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * desc->n_point_lights, &cone_light))) return fail(rc);
-    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri), &sphere_any))) return fail(rc);
-    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_clusters) * desc->n_point_lights, &cl_light))) return fail(rc);
-    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_clusters), &cl_sphere))) return fail(rc);
-    d.cone_light = cone_light;
-    d.sphere_any = sphere_any;
-    d.cl_light = cl_light;
-    d.cl_sphere = cl_sphere;
-    uint32_t* k_of = nullptr;
-    std::vector<uint32_t> order;   // stays alive until the stream has been synchronised below
-    if (d.n_tri) {
-        if (!desc->triangle8s) return fail(rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: triangle8s is null"));
-        order = cluster_order(desc->triangle8s, d.tri_nb);
-        if ((rc = upload(s, order.data(), order.size(), &k_of))) return fail(rc);
-    }
-    d.k_of = k_of;
+    if ((rc = upload<float4>(s, nullptr, d.n_sph, &sph))) return fail(rc);
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * 6, &ell))) return fail(rc);
+    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * desc->n_point_lights, &ell_light))) return fail(rc);
+    d.tri = tri; d.trif = trif; d.sph = sph; d.ell = ell; d.ell_light = ell_light;
     {
         float b = 0.0f;
         for (int i = 0; i < 6; ++i) b = std::fmax(b, std::fabs(desc->bounding_box[i]));
         d.origin_bound = 1.001f * b + 1.0e-3f;
     }
-    if ((rc = upload<float4>(s, nullptr, d.n_sph, &sph))) return fail(rc);
-    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * 6, &ell))) return fail(rc);
-    if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * desc->n_point_lights, &ell_light))) return fail(rc);
     if (d.n_tri) hipLaunchKernelGGL(k_prep_triangles, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, raw_tri, d.tri_nb, tri, trif);
-    if (d.n_tri) {
-        hipLaunchKernelGGL(k_prep_sphere, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, tri, d.k_of, d.n_tri, d.origin_bound, sphere_any);
-        hipLaunchKernelGGL(k_prep_cluster_sphere, dim3(ceil_div(d.n_clusters, BLOCK)), dim3(BLOCK), 0, stream,
-                           static_cast<const float4*>(sphere_any), d.n_tri, d.n_clusters, d.origin_bound, cl_sphere);
-        hipLaunchKernelGGL(k_prep_cluster_sphere, dim3(ceil_div(d.n_tops, BLOCK)), dim3(BLOCK), 0, stream,
-                           static_cast<const float4*>(cl_sphere), d.n_clusters, d.n_tops, d.origin_bound, top_sphere);
-    }
-    for (uint64_t l = 0; d.n_tri && l < desc->n_point_lights; ++l) {
-        const float* L = desc->point_light_sources + l * 6;
-        hipLaunchKernelGGL(k_prep_cone, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, tri, d.k_of, d.n_tri, L[0], L[1], L[2], d.origin_bound, 1,
-                           cone_light + static_cast<size_t>(l) * d.n_tri);
-        hipLaunchKernelGGL(k_prep_cluster_cone, dim3(ceil_div(d.n_clusters, BLOCK)), dim3(BLOCK), 0, stream,
-                           static_cast<const float4*>(cone_light + static_cast<size_t>(l) * d.n_tri), d.n_tri, d.n_clusters, cl_light + static_cast<size_t>(l) * d.n_clusters);
-        hipLaunchKernelGGL(k_prep_cluster_cone, dim3(ceil_div(d.n_tops, BLOCK)), dim3(BLOCK), 0, stream,
-                           static_cast<const float4*>(cl_light + static_cast<size_t>(l) * d.n_clusters), d.n_clusters, d.n_tops, top_light + static_cast<size_t>(l) * d.n_tops);
-    }
     if (d.n_sph) hipLaunchKernelGGL(k_prep_spheres, dim3(ceil_div(d.n_sph, BLOCK)), dim3(BLOCK), 0, stream, raw_sph, d.sph_nb, sph);
     if (d.n_ell) hipLaunchKernelGGL(k_prep_ellipsoids, dim3(ceil_div(d.n_ell, BLOCK)), dim3(BLOCK), 0, stream, raw_inv, raw_fwd, d.ell_nb, ell);
     if (d.n_ell && desc->n_point_lights)
         hipLaunchKernelGGL(k_prep_ellipsoid_lights, dim3(ceil_div(d.n_ell, BLOCK)), dim3(BLOCK), 0, stream, ell, d.n_ell, raw_pl, static_cast<uint32_t>(desc->n_point_lights), ell_light);
-    d.tri = tri; d.trif = trif; d.sph = sph; d.ell = ell; d.ell_light = ell_light;
+
+    // bounding records (see Hierarchy): cluster order on the host, leaf records per kind, then the two levels above
+    std::vector<uint32_t> orders[2];   // stay alive until the stream has been synchronised below
+    const size_t n_pl = desc->n_point_lights;
+    for (int prim = 0; prim < 2; ++prim) {
+        Hierarchy& h = prim == 0 ? d.th : d.eh;
+        rt_scene::EyeRecords& eye = prim == 0 ? s->eye_tri : s->eye_ell;
+        h.n = prim == 0 ? d.n_tri : d.n_ell;
+        h.n_clusters = ceil_div(h.n, CLUSTER);
+        h.n_tops = ceil_div(h.n_clusters, CLUSTER);
+        if (h.n == 0) continue;
+        std::vector<float> centroid;
+        std::vector<uint8_t> good;
+        if (prim == 0) {
+            if (!desc->triangle8s) return fail(rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: triangle8s is null"));
+            triangle_centroids(desc->triangle8s, d.tri_nb, centroid, good);
+        } else {
+            if (!desc->ellipsoid8_transforms || !desc->ellipsoid8_inverse_transforms) return fail(rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: ellipsoid transforms are null"));
+            ellipsoid_centroids(desc->ellipsoid8_transforms, desc->ellipsoid8_inverse_transforms, d.ell_nb, centroid, good);
+        }
+        orders[prim] = cluster_order(centroid, good);
+        uint32_t* k_of;
+        float4 *leaf_light, *leaf_sphere, *cl_light, *cl_sphere, *top_light, *top_sphere;
+        if ((rc = upload(s, orders[prim].data(), orders[prim].size(), &k_of))) return fail(rc);
+        if ((rc = upload<float4>(s, nullptr, h.n, &eye.leaf))) return fail(rc);
+        if ((rc = upload<float4>(s, nullptr, h.n_clusters, &eye.cl))) return fail(rc);
+        if ((rc = upload<float4>(s, nullptr, h.n_tops, &eye.top))) return fail(rc);
+        if ((rc = upload<float4>(s, nullptr, h.n * n_pl, &leaf_light))) return fail(rc);
+        if ((rc = upload<float4>(s, nullptr, h.n_clusters * n_pl, &cl_light))) return fail(rc);
+        if ((rc = upload<float4>(s, nullptr, h.n_tops * n_pl, &top_light))) return fail(rc);
+        if ((rc = upload<float4>(s, nullptr, h.n, &leaf_sphere))) return fail(rc);
+        if ((rc = upload<float4>(s, nullptr, h.n_clusters, &cl_sphere))) return fail(rc);
+        if ((rc = upload<float4>(s, nullptr, h.n_tops, &top_sphere))) return fail(rc);
+        h.k_of = k_of;
+        h.leaf_light = leaf_light; h.cl_light = cl_light; h.top_light = top_light;
+        h.leaf_sphere = leaf_sphere; h.cl_sphere = cl_sphere; h.top_sphere = top_sphere;
+        const dim3 leaf_grid(ceil_div(h.n, BLOCK)), cl_grid(ceil_div(h.n_clusters, BLOCK)), top_grid(ceil_div(h.n_tops, BLOCK));
+        if (prim == 0) hipLaunchKernelGGL(k_prep_sphere, leaf_grid, dim3(BLOCK), 0, stream, tri, h.k_of, h.n, d.origin_bound, leaf_sphere);
+        else hipLaunchKernelGGL(k_prep_ell_sphere, leaf_grid, dim3(BLOCK), 0, stream, ell, h.k_of, h.n, d.origin_bound, leaf_sphere);
+        hipLaunchKernelGGL(k_prep_cluster_sphere, cl_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(leaf_sphere), h.n, h.n_clusters, d.origin_bound, cl_sphere);
+        hipLaunchKernelGGL(k_prep_cluster_sphere, top_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(cl_sphere), h.n_clusters, h.n_tops, d.origin_bound, top_sphere);
+        for (size_t l = 0; l < n_pl; ++l) {
+            const float* L = desc->point_light_sources + l * 6;
+            float4* leaf = leaf_light + l * h.n;
+            if (prim == 0) hipLaunchKernelGGL(k_prep_cone, leaf_grid, dim3(BLOCK), 0, stream, tri, h.k_of, h.n, L[0], L[1], L[2], d.origin_bound, 1, leaf);
+            else hipLaunchKernelGGL(k_prep_ell_cone, leaf_grid, dim3(BLOCK), 0, stream, ell, h.k_of, h.n, L[0], L[1], L[2], d.origin_bound, 1, leaf);
+            hipLaunchKernelGGL(k_prep_cluster_cone, cl_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(leaf), h.n, h.n_clusters, cl_light + l * h.n_clusters);
+            hipLaunchKernelGGL(k_prep_cluster_cone, top_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(cl_light + l * h.n_clusters), h.n_clusters, h.n_tops, top_light + l * h.n_tops);
+        }
+    }
 
     // light table: the directional light first (ray_tracing.cpp:687), then the point lights in file order (:704)
     std::vector<float> lights;
