@@ -21,7 +21,7 @@ def _fmt(a):
 
 
 def write_scene(path, n_triangles=1_000_000, n_ellipsoids=10_000, n_lights=8, width=3840, height=2160,
-                maxdepth=2, seed=1, extent=10.0, edge=0.15, materials_every=1000):
+                maxdepth=2, seed=1, extent=10.0, edge=0.15, materials_every=1000, ell_scale=(0.05, 0.3)):
     """Writes the scene; returns the path.  Deterministic in its arguments."""
     rng_t = np.random.Generator(np.random.PCG64(seed))
     rng_e = np.random.Generator(np.random.PCG64(seed + 1))
@@ -75,8 +75,8 @@ def write_scene(path, n_triangles=1_000_000, n_ellipsoids=10_000, n_lights=8, wi
         axis /= np.linalg.norm(axis)
         angle = rng_e.uniform(0.0, 360.0)
         while True:
-            sc = rng_e.uniform(0.05, 0.3, 3)
-            if min(abs(sc[0] - sc[1]), abs(sc[1] - sc[2]), abs(sc[0] - sc[2])) > 5e-3:
+            sc = rng_e.uniform(ell_scale[0], ell_scale[1], 3)
+            if min(abs(sc[0] - sc[1]), abs(sc[1] - sc[2]), abs(sc[0] - sc[2])) > 0.02 * (ell_scale[1] - ell_scale[0]):
                 break
         lines.append("pushTransform")
         lines.append("translate %.6f %.6f %.6f" % tuple(t))
@@ -96,7 +96,7 @@ def write_scene(path, n_triangles=1_000_000, n_ellipsoids=10_000, n_lights=8, wi
 def ensure_scene_file(directory=None, **kwargs):
     """Path of the scene for these parameters, generated on first use (about a minute for the full size)."""
     directory = directory or os.environ.get("RT_SYNTH_DIR") or tempfile.gettempdir()
-    tag = "_".join("%s%s" % (k[:3], kwargs[k]) for k in sorted(kwargs)) or "default"
+    tag = "_".join("%s%s" % (k[:3], str(kwargs[k]).replace(" ", "").replace("(", "").replace(")", "").replace(",", "-")) for k in sorted(kwargs)) or "default"
     path = os.path.join(directory, "rt_synthetic_%s.test" % tag)
     if not os.path.exists(path):
         write_scene(path, **kwargs)
