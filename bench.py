@@ -33,6 +33,8 @@ def parse_args():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--maxdepth", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunk-tiles", type=int, default=0, help="tiles per chunk of ray state (0 = library default)")
+    ap.add_argument("--brute-force", action="store_true", help="RT_FLAG_NO_FILTER: every ray-primitive pair through the literal full test")
     ap.add_argument("--cpu-crop", default="240x135", help="centred crop the CPU baseline renders (WxH)")
     return ap.parse_args()
 
@@ -88,7 +90,8 @@ def main():
     depth = fi.max_recursion_depth if args.maxdepth < 0 else args.maxdepth
     cam = fi.camera()
     scene = api.Scene(fi.scene_desc)
-    prm = fi.params(max_bounce_count=depth, tile_rank=rank, tile_world=world)
+    flags = abi.RT_FLAG_NO_FILTER if args.brute_force else 0
+    prm = fi.params(max_bounce_count=depth, tile_rank=rank, tile_world=world, flags=flags, chunk_tiles=args.chunk_tiles)
     stride = distributed.stride_tiles(prm, world)      # tiles per rank in the gathered buffer
     assert api.rank_tile_count(prm) == len(distributed.rank_tiles(prm, rank, world)) <= stride
 
@@ -181,7 +184,9 @@ def main():
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": closest_tflops / PEAK_FP32_TFLOPS,
-                "traffic": None,
+                "traffic": measured_traffic(label, args.brute_force),
+                "mode": "brute force (literal full test on every pair)" if args.brute_force else "bounding hierarchy + conservative pre-tests, full test on the survivors",
+                "note": ROOFLINE_NOTE,
                 "flop_per_launch": closest_flop / max(tot["closest_launches"], 1.0),
                 "avg_launch_ms": tot["closest_ms"] / max(tot["closest_launches"], 1.0),
                 "launches": int(tot["closest_launches"]),
@@ -199,6 +204,20 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+ROOFLINE_NOTE = ("achieved = ray-primitive tests x FLOP of the reference formulation (54 triangle, 19 sphere, 95 ellipsoid) / HIP-event time of the "
+                 "closest-hit scan launches; in the default mode most tests are decided by bounds, so frac is above 1 and is not a utilisation: "
+                 "executed VALU utilisation (PMC) is in profiles/")
+
+
+def measured_traffic(label, brute_force):
+    """HBM bytes per closest-hit scan launch of this workload from the committed rocprofv3 PMC pass (profiles/traffic.json), or None."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return table.get(label + ("/brute-force" if brute_force else ""))
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(api, abi, fi, cam, scene, depth, crop):

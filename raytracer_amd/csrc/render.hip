@@ -88,6 +88,7 @@ struct Hierarchy {
 struct DevScene {
     const float4* tri;   // 4 x float4 per triangle: (a, n.x) (a_to_b, n.y) (a_to_c, n.z) (n.n, 0, 0, 0)
     const float4* trif;  // pre-test records, 4 x float4 per triangle, see pretest_stage1
+    const float4* trif_pos;  // the same in cluster order (th.k_of), with the scan index in the spare word [2].w
     Hierarchy th;        // bounding records of the triangles, see Hierarchy
     Hierarchy eh;        // bounding records of the ellipsoids
     const float4* sph;   // (centre, radius)
@@ -526,6 +527,17 @@ __global__ void __launch_bounds__(BLOCK) k_prep_triangles(const float* __restric
     q[1] = make_float4(a.x, a.y, a.z, 2.0f * H + 0.5f);
     q[2] = make_float4(w1.x, w1.y, w1.z, 0.0f);
     q[3] = make_float4(w2.x, w2.y, w2.z, 0.0f);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_reorder_pretest_records(const float4* __restrict__ trif, const uint32_t* __restrict__ k_of, uint32_t n, float4* __restrict__ out) {
+    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
+    if (pos >= n) return;
+    const uint32_t k = k_of[pos];
+    const float4* f = trif + static_cast<size_t>(k) * 4;
+    float4* o = out + static_cast<size_t>(pos) * 4;
+    o[0] = f[0]; o[1] = f[1];
+    o[2] = make_float4(f[2].x, f[2].y, f[2].z, __uint_as_float(k));
+    o[3] = f[3];
 }
 
 // Cone records (cone_keeps) for rays through X.  `reversed` = 0: X is the camera eye, the full
@@ -1075,12 +1087,16 @@ DEV void push_bits(uint32_t* q, uint32_t& count, uint32_t bits, uint32_t n_bits,
     }
 }
 
-// two-stage pre-test and, if it keeps the ray, the full test; FLT_MAX otherwise
-DEV float pretests_then_full(const DevScene& sc, uint32_t k, V3 o, V3 d, uint32_t& n_full) {
-    const float4* __restrict__ f = sc.trif + static_cast<size_t>(k) * 4;
+// two-stage pre-test and, if it keeps the ray, the full test; FLT_MAX otherwise.  `pos` is the
+// triangle's position in cluster order; its pre-test record carries the scan index k, so that the
+// full-test record is only looked up for the pairs that need it.
+DEV float pretests_then_full(const DevScene& sc, uint32_t pos, V3 o, V3 d, uint32_t& n_full, uint32_t& k) {
+    const float4* __restrict__ f = sc.trif_pos + static_cast<size_t>(pos) * 4;
+    const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
+    k = __float_as_uint(f2.w);
     Pre pre;
     const float o_max = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
-    if (!(pretest_stage1(o, d, o_max, f[0], f[1], f[2], pre) && pretest_stage2(pre, f[3]))) return FLT_MAX;
+    if (!(pretest_stage1(o, d, o_max, f0, f1, f2, pre) && pretest_stage2(pre, f3))) return FLT_MAX;
     const float4* __restrict__ rec = sc.tri + static_cast<size_t>(k) * 4;
     n_full++;
     return hit_triangle(o, d, rec[0], rec[1], rec[2], rec[3].x);
@@ -1183,13 +1199,15 @@ __global__ void __launch_bounds__(BLOCK) k_closest_scan(DevScene sc, State st, u
         wave_sync();
         for (uint32_t i = lane; i < q2_count; i += 64) {
             const uint32_t e = q2[i];
-            const uint32_t s = wave_slots[e >> 24], k = h.k_of[e & NODE_MASK];
+            const uint32_t s = wave_slots[e >> 24];
             const V3 o{st.ox[s], st.oy[s], st.oz[s]};
             const V3 dd{st.dx[s], st.dy[s], st.dz[s]};
             if (PRIM == 0) {
-                const float t = pretests_then_full(sc, k, o, dd, n_full);
+                uint32_t k;
+                const float t = pretests_then_full(sc, e & NODE_MASK, o, dd, n_full, k);
                 if (t < FLT_MAX) atomicMin(&st.key[s], pack_hit(t, k));
             } else {
+                const uint32_t k = h.k_of[e & NODE_MASK];
                 const float4* __restrict__ rec = sc.ell + static_cast<size_t>(k) * 6;
                 const float t = hit_ellipsoid(o, dd, rec[0], rec[1], rec[2], rec[3], rec[4], rec[5]);
                 n_full++;
@@ -1214,20 +1232,25 @@ __global__ void __launch_bounds__(BLOCK) k_closest_scan(DevScene sc, State st, u
             if (MODE == 3) dd = normalise(dd);
             const V3 mm = scross(o, dd);
             const uint32_t last = n_child - 1u;
+            static_assert(CLUSTER % 8 == 0, "the walk takes 8 children at a time");
 #pragma nounroll
-            for (uint32_t t0 = 0; t0 < CLUSTER; t0 += 4) {     // not unrolled: one copy of the code behind drain_out
-                float4 rec[4];
+            for (uint32_t t0 = 0; t0 < CLUSTER; t0 += 8) {     // 8 records in flight per lane
+                float4 rec[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) rec[u] = child[min(first + t0 + u, last)];
+                for (int u = 0; u < 8; ++u) rec[u] = child[min(first + t0 + u, last)];
                 uint32_t keep_bits = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const bool keep = active && first + t0 + u <= last && ((MODE == 2 ? cone_keeps(dd, rec[u]) : sphere_keeps(dd, mm, rec[u])) || keep_all);
                     keep_bits |= keep ? 1u << u : 0u;
                 }
-                if (__any(keep_bits != 0u)) {
-                    if (out_count + PUSH_MAX > QCAP) drain_out();
-                    push_bits(q_out, out_count, keep_bits, 4u, (e & ~NODE_MASK) | (first + t0), 1u);
+#pragma nounroll
+                for (uint32_t half = 0; half < 2; ++half) {     // not unrolled: one copy of the code behind drain_out
+                    const uint32_t bits = (keep_bits >> (4u * half)) & 15u;
+                    if (__any(bits != 0u)) {
+                        if (out_count + PUSH_MAX > QCAP) drain_out();
+                        push_bits(q_out, out_count, bits, 4u, (e & ~NODE_MASK) | (first + t0 + 4u * half), 1u);
+                    }
                 }
             }
         }
@@ -1574,12 +1597,14 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_scan(DevScene sc, State st, ui
         wave_sync();
         for (uint32_t i = lane; i < q2_count; i += 64) {
             const uint32_t e = q2[i];
-            const uint32_t ray = e >> 24, k = h.k_of[e & NODE_MASK];
+            const uint32_t ray = e >> 24;
             const ShadowRay s = make_shadow_ray(st, wave_slots[ray], point, lv);
             bool blocks;
             if (PRIM == 0) {
-                blocks = pretests_then_full(sc, k, s.o, s.d, n_full) < s.limit;
+                uint32_t k;
+                blocks = pretests_then_full(sc, e & NODE_MASK, s.o, s.d, n_full, k) < s.limit;
             } else {
+                const uint32_t k = h.k_of[e & NODE_MASK];
                 const float4* __restrict__ rec = sc.ell + static_cast<size_t>(k) * 6;
                 const V3 l2 = point ? xyz(sc.ell_light[static_cast<size_t>(light - sc.has_directional) * sc.n_ell + k]) : V3{0.0f, 0.0f, 0.0f};
                 blocks = ellipsoid_blocks(s.o, s.d, rec[0], rec[1], rec[2], point, l2);
@@ -1607,20 +1632,25 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_scan(DevScene sc, State st, ui
             const ShadowRay s = make_shadow_ray(st, wave_slots[e >> 24], point, lv);
             const V3 mm = scross(s.o, s.d);
             const uint32_t last = n_child - 1u;
+            static_assert(CLUSTER % 8 == 0, "the walk takes 8 children at a time");
 #pragma nounroll
-            for (uint32_t t0 = 0; t0 < CLUSTER; t0 += 4) {     // not unrolled: one copy of the code behind drain_out
-                float4 rec[4];
+            for (uint32_t t0 = 0; t0 < CLUSTER; t0 += 8) {     // 8 records in flight per lane
+                float4 rec[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) rec[u] = child[min(first + t0 + u, last)];
+                for (int u = 0; u < 8; ++u) rec[u] = child[min(first + t0 + u, last)];
                 uint32_t keep_bits = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const bool keep = active && first + t0 + u <= last && ((MODE == 2 ? cone_keeps(s.d, rec[u]) : sphere_keeps(s.d, mm, rec[u])) || keep_all);
                     keep_bits |= keep ? 1u << u : 0u;
                 }
-                if (__any(keep_bits != 0u)) {
-                    if (out_count + PUSH_MAX > QCAP) drain_out();
-                    push_bits(q_out, out_count, keep_bits, 4u, (e & ~NODE_MASK) | (first + t0), 1u);
+#pragma nounroll
+                for (uint32_t half = 0; half < 2; ++half) {     // not unrolled: one copy of the code behind drain_out
+                    const uint32_t bits = (keep_bits >> (4u * half)) & 15u;
+                    if (__any(bits != 0u)) {
+                        if (out_count + PUSH_MAX > QCAP) drain_out();
+                        push_bits(q_out, out_count, bits, 4u, (e & ~NODE_MASK) | (first + t0 + 4u * half), 1u);
+                    }
                 }
             }
         }
@@ -1894,22 +1924,22 @@ Library g_lib;
 #define RT_RAYS_PER_LANE 2
 #endif
 #ifndef RT_R_CONE
-#define RT_R_CONE 4
+#define RT_R_CONE 2
 #endif
 #ifndef RT_R_STRIP
-#define RT_R_STRIP 4
+#define RT_R_STRIP 2
 #endif
 #ifndef RT_R_SHADOW_CONE
-#define RT_R_SHADOW_CONE 4
+#define RT_R_SHADOW_CONE 2
 #endif
 #ifndef RT_R_SHADOW_STRIP
-#define RT_R_SHADOW_STRIP 4
+#define RT_R_SHADOW_STRIP 2
 #endif
 constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;   // full-test, sphere and ellipsoid scans
 // The pre-test scans execute so few instructions per test that the LDS broadcast reads of the
 // records (4 LDS cycles per float4 per wave) only stay hidden with several rays per lane.
 constexpr int R_CONE = RT_R_CONE, R_STRIP = RT_R_STRIP, R_SHADOW_CONE = RT_R_SHADOW_CONE, R_SHADOW_STRIP = RT_R_SHADOW_STRIP;
-constexpr uint32_t DEFAULT_CHUNK_TILES = 8192;   // 33.5 M samples, 3.6 GB of ray state
+constexpr uint32_t DEFAULT_CHUNK_TILES = 32768;   // 134 M samples, 14.5 GB of ray state: a 3840x2160 frame in one chunk (long launches hide the tail of the slowest waves)
 constexpr uint32_t MAX_BOUNCES = 62;
 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
@@ -2371,6 +2401,12 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
         h.leaf_light = leaf_light; h.cl_light = cl_light; h.top_light = top_light;
         h.leaf_sphere = leaf_sphere; h.cl_sphere = cl_sphere; h.top_sphere = top_sphere;
         const dim3 leaf_grid(ceil_div(h.n, BLOCK)), cl_grid(ceil_div(h.n_clusters, BLOCK)), top_grid(ceil_div(h.n_tops, BLOCK));
+        if (prim == 0) {
+            float4* trif_pos;
+            if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n) * 4, &trif_pos))) return fail(rc);
+            hipLaunchKernelGGL(k_reorder_pretest_records, leaf_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(trif), h.k_of, h.n, trif_pos);
+            d.trif_pos = trif_pos;
+        }
         if (prim == 0) hipLaunchKernelGGL(k_prep_sphere, leaf_grid, dim3(BLOCK), 0, stream, tri, h.k_of, h.n, d.origin_bound, leaf_sphere);
         else hipLaunchKernelGGL(k_prep_ell_sphere, leaf_grid, dim3(BLOCK), 0, stream, ell, h.k_of, h.n, d.origin_bound, leaf_sphere);
         hipLaunchKernelGGL(k_prep_cluster_sphere, cl_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(leaf_sphere), h.n, h.n_clusters, d.origin_bound, cl_sphere);
