@@ -14,7 +14,8 @@ PMCARGS="--steps 1 --warmup 0 --no-cpu-baseline"
 echo "== pmc sq" && timeout -s KILL 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY -d "$OUT/pmc_sq" -o pmc -- python3 "$ROOT/bench.py" $PMCARGS > "$OUT/pmc_sq.log" 2>&1 || { echo "pmc sq failed"; tail -5 "$OUT/pmc_sq.log"; exit 1; }
 echo "== pmc fetch" && timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum -d "$OUT/pmc_fetch" -o pmc -- python3 "$ROOT/bench.py" $PMCARGS > "$OUT/pmc_fetch.log" 2>&1 || { echo "pmc fetch failed"; tail -5 "$OUT/pmc_fetch.log"; exit 1; }
 echo "== pmc write" && timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d "$OUT/pmc_write" -o pmc -- python3 "$ROOT/bench.py" $PMCARGS > "$OUT/pmc_write.log" 2>&1 || { echo "pmc write failed"; tail -5 "$OUT/pmc_write.log"; exit 1; }
-find "$OUT" -name "*.csv" | head -20
+echo "== brute force (every pair through the literal full test), 1280x720" && timeout -k 10 300 python3 "$ROOT/bench.py" --brute-force --width 1280 --height 720 --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/brute_force.log" 2>&1 || { echo "brute force failed"; tail -5 "$OUT/brute_force.log"; exit 1; }
+echo "== synthetic scene" && timeout -k 10 300 python3 "$ROOT/bench.py" --workload synthetic --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/synthetic.log" 2>&1 || { echo "synthetic failed"; tail -5 "$OUT/synthetic.log"; exit 1; }
 # keep the merge small: drop anything huge
 find "$OUT" -size +20M -delete
 du -sh "$OUT"

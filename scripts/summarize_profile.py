@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 sqlite outputs of scripts/profile.sh into the text summaries kept under profiles/.
 
-    python scripts/summarize_profile.py gpurun_out/prof_<tag> profiles/<name>
+    python scripts/summarize_profile.py gpurun_out/prof_<tag> profiles/<name> [profiles/traffic.json]
 """
 import glob
+import json
 import os
 import sqlite3
 import sys
@@ -77,12 +78,27 @@ def main():
             if g("GRBM_GUI_ACTIVE") is not None:
                 n, total, dur = cs["GRBM_GUI_ACTIVE"]
                 out.append("  derived: effective clock = GUI_ACTIVE/8/duration = %.3f GHz" % (total / 8.0 / dur))
-    for log in ("trace.log", "pmc_sq.log"):
+    for log in ("trace.log", "pmc_sq.log", "brute_force.log", "synthetic.log"):
         path = os.path.join(src, log)
         if os.path.exists(path):
             for line in open(path):
                 if line.startswith('{"metric"'):
                     out.append("\n== bench.py line of the %s run\n%s" % (log.replace(".log", ""), line.strip()))
+    # HBM bytes per closest-hit scan launch (what bench.py reports as roofline.traffic), keyed by the workload of the PMC runs
+    closest = [cs for kernel, cs in merged.items() if "k_closest_scan" in kernel and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs]
+    label = None
+    for line in open(os.path.join(src, "pmc_sq.log")) if os.path.exists(os.path.join(src, "pmc_sq.log")) else []:
+        if line.startswith('{"metric"'):
+            label = json.loads(line)["config"]["workload"]
+    if closest and label and len(sys.argv) > 3:
+        launches = sum(cs["FETCH_SIZE"][0] for cs in closest)
+        total = sum(2.0 * 1024.0 * cs["FETCH_SIZE"][1] + 1024.0 * cs["WRITE_SIZE"][1] for cs in closest)
+        table = {}
+        if os.path.exists(sys.argv[3]):
+            table = json.load(open(sys.argv[3]))
+        table[label] = total / launches
+        json.dump(table, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+        out.append("\n== HBM bytes per closest-hit scan launch (%s): %.4e  -> %s" % (label, total / launches, sys.argv[3]))
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     with open(dst, "w") as f:
         f.write("\n".join(out) + "\n")
