@@ -131,10 +131,14 @@ struct State {
     uint32_t* counts;                     // counts[b]: live rays entering bounce b
     unsigned long long* flag_bits;        // per producing workgroup: 4 wave ballots of "this entry goes on" (ordered compaction)
     uint32_t* wg_offset;                  // per producing workgroup: position of its first entry in the next list
+    uint32_t* scan_block;                 // per 1024 producing workgroups: their total, then the position of their first entry
     uint32_t* primary_id;                 // nullable
     unsigned long long* stats;            // ST_* counters
 };
 
+// Work counters live in STAT_COPIES copies, picked by workgroup number and summed by the host:
+// one hot address per counter serialises the atomics of a whole launch (10 ns each).
+constexpr int STAT_COPIES = 64;
 enum { ST_SAMPLES, ST_CULLED, ST_CLOSEST_RAYS, ST_HITS, ST_SHADOW_RAYS, ST_SHADOW_BLOCKED,
        ST_SHADOW_TESTS_TRI, ST_SHADOW_TESTS_SPH, ST_SHADOW_TESTS_ELL, ST_FULL_TESTS, ST_PAIR_PRETESTS, ST_PAIR_PRETESTS_SHADOW, ST_LIVE, ST_QUEUED, ST_QUEUED_SHADOW, ST_COUNT };
 
@@ -491,6 +495,7 @@ DEV bool ellipsoid_blocks(V3 o, V3 d, float4 i0, float4 i1, float4 i2, bool poin
 // ------------------------------------------------------------------------------------------
 // workgroup helpers
 // ------------------------------------------------------------------------------------------
+DEV unsigned long long* stat_slot(const State& st, int which) { return st.stats + (blockIdx.x & (STAT_COPIES - 1)) * ST_COUNT + which; }
 DEV void block_add_stat(unsigned long long* stat, unsigned long long value) {
     // wave reduction, then one atomic per wave
     for (int off = 32; off > 0; off >>= 1) value += __shfl_down(value, off);
@@ -941,20 +946,13 @@ __global__ void __launch_bounds__(BLOCK) k_primary(Frame f, DevScene sc, State s
 // in the image, which is what makes the per-wave pre-test of the scans narrow.  (Appending with one
 // atomic per workgroup leaves the workgroups in their completion order, scattered over the part
 // of the image that is in flight.)
-// k_scan_flags: one workgroup; exclusive prefix of the per-workgroup flag counts, and the total.
+// k_scan_flags: per block of SCAN_THREADS producing workgroups, the exclusive prefix of their flag
+// counts (wg_offset) and the block's total (scan_block[b]).
+// k_scan_blocks: one workgroup; exclusive prefix over the block totals in place, the list length,
+// and the work counters that are list lengths (one atomic per launch instead of one per wave).
 constexpr int SCAN_THREADS = 1024;
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_flags(State st, const uint32_t* __restrict__ n_in_ptr, uint32_t n_in_fixed, uint32_t* __restrict__ n_out, int stat_in, int stat_out) {
-    __shared__ uint32_t partial[SCAN_THREADS];
-    const uint32_t n_in = n_in_ptr ? *n_in_ptr : n_in_fixed;
-    const uint32_t n_wg = (n_in + BLOCK - 1) / BLOCK;
-    const uint32_t per = (n_wg + SCAN_THREADS - 1) / SCAN_THREADS;
-    const uint32_t begin = min(n_wg, threadIdx.x * per), end = min(n_wg, begin + per);
-    uint32_t sum = 0;
-    for (uint32_t g = begin; g < end; ++g) {
-        const ulonglong2 a = reinterpret_cast<const ulonglong2*>(st.flag_bits)[g * 2u], b = reinterpret_cast<const ulonglong2*>(st.flag_bits)[g * 2u + 1u];
-        sum += __popcll(a.x) + __popcll(a.y) + __popcll(b.x) + __popcll(b.y);
-    }
-    partial[threadIdx.x] = sum;
+DEV uint32_t block_exclusive_scan(uint32_t value, uint32_t* partial /* SCAN_THREADS words */, uint32_t& total) {
+    partial[threadIdx.x] = value;
     __syncthreads();
     for (uint32_t step = 1; step < SCAN_THREADS; step <<= 1) {      // inclusive Hillis-Steele scan
         const uint32_t add = threadIdx.x >= step ? partial[threadIdx.x - step] : 0u;
@@ -962,17 +960,38 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_flags(State st, const uin
         partial[threadIdx.x] += add;
         __syncthreads();
     }
-    uint32_t running = partial[threadIdx.x] - sum;
-    for (uint32_t g = begin; g < end; ++g) {
+    total = partial[SCAN_THREADS - 1];
+    return partial[threadIdx.x] - value;
+}
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_flags(State st, const uint32_t* __restrict__ n_in_ptr, uint32_t n_in_fixed) {
+    __shared__ uint32_t partial[SCAN_THREADS];
+    const uint32_t n_in = n_in_ptr ? *n_in_ptr : n_in_fixed;
+    const uint32_t n_wg = (n_in + BLOCK - 1) / BLOCK;
+    if (blockIdx.x * SCAN_THREADS >= n_wg) return;
+    const uint32_t g = blockIdx.x * SCAN_THREADS + threadIdx.x;
+    uint32_t count = 0;
+    if (g < n_wg) {
         const ulonglong2 a = reinterpret_cast<const ulonglong2*>(st.flag_bits)[g * 2u], b = reinterpret_cast<const ulonglong2*>(st.flag_bits)[g * 2u + 1u];
-        st.wg_offset[g] = running;
-        running += __popcll(a.x) + __popcll(a.y) + __popcll(b.x) + __popcll(b.y);
+        count = __popcll(a.x) + __popcll(a.y) + __popcll(b.x) + __popcll(b.y);
     }
-    if (threadIdx.x == SCAN_THREADS - 1) {
-        *n_out = partial[SCAN_THREADS - 1];
-        // the work counters that are list lengths are kept here: one atomic per launch instead of one per wave
-        if (stat_in >= 0) atomicAdd(&st.stats[stat_in], static_cast<unsigned long long>(n_in));
-        if (stat_out >= 0) atomicAdd(&st.stats[stat_out], static_cast<unsigned long long>(partial[SCAN_THREADS - 1]));
+    uint32_t total;
+    const uint32_t before = block_exclusive_scan(count, partial, total);
+    if (g < n_wg) st.wg_offset[g] = before;
+    if (threadIdx.x == 0) st.scan_block[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_blocks(State st, const uint32_t* __restrict__ n_in_ptr, uint32_t n_in_fixed, uint32_t* __restrict__ n_out, int stat_in, int stat_out) {
+    __shared__ uint32_t partial[SCAN_THREADS];
+    const uint32_t n_in = n_in_ptr ? *n_in_ptr : n_in_fixed;
+    const uint32_t n_wg = (n_in + BLOCK - 1) / BLOCK;
+    const uint32_t n_blocks = (n_wg + SCAN_THREADS - 1) / SCAN_THREADS;   // <= SCAN_THREADS: a chunk has at most 2^20 producing workgroups
+    const uint32_t mine = threadIdx.x < n_blocks ? st.scan_block[threadIdx.x] : 0u;
+    uint32_t total;
+    const uint32_t before = block_exclusive_scan(mine, partial, total);
+    if (threadIdx.x < n_blocks) st.scan_block[threadIdx.x] = before;
+    if (threadIdx.x == 0) {
+        *n_out = total;
+        if (stat_in >= 0) atomicAdd(stat_slot(st, stat_in), static_cast<unsigned long long>(n_in));
+        if (stat_out >= 0) atomicAdd(stat_slot(st, stat_out), static_cast<unsigned long long>(total));
     }
 }
 // k_fill_list: workgroup g places the flagged ones of entries g*256.. (the entry itself from list_in, or its index).
@@ -982,7 +1001,7 @@ __global__ void __launch_bounds__(BLOCK) k_fill_list(State st, const uint32_t* _
     const uint32_t base = blockIdx.x * BLOCK;
     if (base >= n_in) return;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint32_t pos = st.wg_offset[blockIdx.x];
+    uint32_t pos = st.scan_block[blockIdx.x / SCAN_THREADS] + st.wg_offset[blockIdx.x];
     for (uint32_t w = 0; w < wave; ++w) pos += __popcll(st.flag_bits[blockIdx.x * 4u + w]);
     const unsigned long long mask = st.flag_bits[blockIdx.x * 4u + wave];
     if ((mask >> lane) & 1ull) {
@@ -1282,9 +1301,9 @@ __global__ void __launch_bounds__(BLOCK) k_closest_scan(DevScene sc, State st, u
     drain0();
     drain1();
     drain2();
-    if (PRIM == 0) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
-    if (lane == 0 && n_pairs) atomicAdd(&st.stats[ST_PAIR_PRETESTS], n_pairs);
-    if (lane == 0 && n_queued) atomicAdd(&st.stats[ST_QUEUED], static_cast<unsigned long long>(n_queued));
+    if (PRIM == 0) block_add_stat(stat_slot(st, ST_FULL_TESTS), n_full);
+    if (lane == 0 && n_pairs) atomicAdd(stat_slot(st, ST_PAIR_PRETESTS), n_pairs);
+    if (lane == 0 && n_queued) atomicAdd(stat_slot(st, ST_QUEUED), static_cast<unsigned long long>(n_queued));
 }
 
 template <int R>
@@ -1721,10 +1740,10 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_scan(DevScene sc, State st, ui
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if (valid[r] && blocked[r]) atomicOr(&st.blocked[slot[r]], light_bit);
-    if ((threadIdx.x & 63u) == 0 && wave_tests) atomicAdd(&st.stats[PRIM == 0 ? ST_SHADOW_TESTS_TRI : ST_SHADOW_TESTS_ELL], wave_tests);
-    if (MODE != 0 && PRIM == 0) block_add_stat(&st.stats[ST_FULL_TESTS], n_full);
-    if ((threadIdx.x & 63u) == 0 && n_pairs) atomicAdd(&st.stats[ST_PAIR_PRETESTS_SHADOW], n_pairs);
-    if ((threadIdx.x & 63u) == 0 && n_queued) atomicAdd(&st.stats[ST_QUEUED_SHADOW], static_cast<unsigned long long>(n_queued));
+    if ((threadIdx.x & 63u) == 0 && wave_tests) atomicAdd(stat_slot(st, PRIM == 0 ? ST_SHADOW_TESTS_TRI : ST_SHADOW_TESTS_ELL), wave_tests);
+    if (MODE != 0 && PRIM == 0) block_add_stat(stat_slot(st, ST_FULL_TESTS), n_full);
+    if ((threadIdx.x & 63u) == 0 && n_pairs) atomicAdd(stat_slot(st, ST_PAIR_PRETESTS_SHADOW), n_pairs);
+    if ((threadIdx.x & 63u) == 0 && n_queued) atomicAdd(stat_slot(st, ST_QUEUED_SHADOW), static_cast<unsigned long long>(n_queued));
 }
 
 template <int R>
@@ -1755,7 +1774,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_sph(DevScene sc, State st, uin
             done = shadow_wave_done<R>(s);
         }
     }
-    store_shadow_result<R>(st, s, light_bit, &st.stats[ST_SHADOW_TESTS_SPH], wave_tests);
+    store_shadow_result<R>(st, s, light_bit, stat_slot(st, ST_SHADOW_TESTS_SPH), wave_tests);
 }
 
 template <int R>
@@ -1793,7 +1812,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_ell(DevScene sc, State st, uin
             done = shadow_wave_done<R>(s);
         }
     }
-    store_shadow_result<R>(st, s, light_bit, &st.stats[ST_SHADOW_TESTS_ELL], wave_tests);
+    store_shadow_result<R>(st, s, light_bit, stat_slot(st, ST_SHADOW_TESTS_ELL), wave_tests);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1820,8 +1839,8 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, State st, uint32_t
     float w[3] = {st.wr[s], st.wg[s], st.wb[s]};
     const V3 to_eye = scale(-1.0f, d);                                    // ray_tracing.cpp:684
     const uint32_t blocked = st.blocked[s];
-    block_add_stat(&st.stats[ST_SHADOW_RAYS], valid ? n_group : 0u);
-    block_add_stat(&st.stats[ST_SHADOW_BLOCKED], valid ? __popc(blocked & (n_group >= 32 ? 0xFFFFFFFFu : ((1u << n_group) - 1u))) : 0);
+    block_add_stat(stat_slot(st, ST_SHADOW_RAYS), valid ? n_group : 0u);
+    block_add_stat(stat_slot(st, ST_SHADOW_BLOCKED), valid ? __popc(blocked & (n_group >= 32 ? 0xFFFFFFFFu : ((1u << n_group) - 1u))) : 0);
 
     for (uint32_t g = 0; g < n_group; ++g) {
         if (blocked & (1u << g)) continue;
@@ -1915,7 +1934,7 @@ struct Library {
     void* state_mem = nullptr;
     size_t state_samples = 0;
     uint32_t* counts = nullptr;             // 64 words
-    unsigned long long* stats = nullptr;    // ST_COUNT words
+    unsigned long long* stats = nullptr;    // STAT_COPIES x ST_COUNT words
     std::vector<hipEvent_t> events;
 };
 Library g_lib;
@@ -1980,7 +1999,7 @@ int ensure_state(size_t samples) {
     if (g_lib.state_mem) { HIP_TRY(hipFree(g_lib.state_mem)); g_lib.state_mem = nullptr; g_lib.state_samples = 0; }
     // 18 float arrays + hit_id + blocked + 2 lists + primary ids + two 64-bit keys = 27 words per sample
     // + per 256 samples: 4 wave ballots and one offset (ordered compaction)
-    HIP_TRY(hipMalloc(&g_lib.state_mem, samples * 27 * sizeof(float) + samples / BLOCK * 40));
+    HIP_TRY(hipMalloc(&g_lib.state_mem, samples * 27 * sizeof(float) + samples / BLOCK * 40 + SCAN_THREADS * sizeof(uint32_t)));
     g_lib.state_samples = samples;
     return 0;
 }
@@ -1999,6 +2018,7 @@ State make_state(size_t samples, bool want_ids) {
     st.key_ell = st.key + samples;
     st.flag_bits = st.key_ell + samples;                               // 16-byte aligned likewise
     st.wg_offset = reinterpret_cast<uint32_t*>(st.flag_bits + samples / BLOCK * 4);
+    st.scan_block = st.wg_offset + samples / BLOCK + samples / BLOCK % 2;   // after the offsets (8 bytes of the 40 per workgroup are spare)
     st.counts = g_lib.counts;
     st.stats = g_lib.stats;
     return st;
@@ -2081,7 +2101,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     f.tiles_x = rect.tiles_x; f.tile_rank = prm->tile_rank; f.tile_world = world;
 
     State st = make_state(chunk_samples, ids_dev != nullptr);
-    HIP_TRY(hipMemsetAsync(g_lib.stats, 0, ST_COUNT * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(g_lib.stats, 0, STAT_COPIES * ST_COUNT * sizeof(unsigned long long), stream));
 
     Timer timer_storage;
     Timer* timer = stats ? &timer_storage : nullptr;
@@ -2095,7 +2115,9 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         const uint32_t n_samples = n_tiles * SAMPLES_PER_TILE;
         HIP_TRY(hipMemsetAsync(g_lib.counts, 0, 64 * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(k_primary, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, f, sc, st, first);
-        hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(nullptr), n_samples, st.counts, -1, static_cast<int>(ST_LIVE));
+        const uint32_t scan_grid = ceil_div(n_samples / BLOCK, SCAN_THREADS);
+        hipLaunchKernelGGL(k_scan_flags, dim3(scan_grid), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(nullptr), n_samples);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(nullptr), n_samples, st.counts, -1, static_cast<int>(ST_LIVE));
         hipLaunchKernelGGL(k_fill_list, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, st, static_cast<const uint32_t*>(nullptr), n_samples,
                            static_cast<const uint32_t*>(nullptr), st.list[0]);
         const uint32_t scan_blocks = ceil_div(n_samples, BLOCK * RAYS_PER_LANE);
@@ -2119,7 +2141,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                 }
             });
             hipLaunchKernelGGL(k_hit, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-            hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(st.counts + b), 0u, st.counts + b + 1,
+            hipLaunchKernelGGL(k_scan_flags, dim3(scan_grid), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(st.counts + b), 0u);
+            hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(st.counts + b), 0u, st.counts + b + 1,
                                static_cast<int>(ST_CLOSEST_RAYS), static_cast<int>(ST_HITS));
             hipLaunchKernelGGL(k_fill_list, dim3(ray_blocks), dim3(BLOCK), 0, stream, st, static_cast<const uint32_t*>(st.counts + b), 0u,
                                static_cast<const uint32_t*>(st.list[b & 1u]), st.list[(b + 1) & 1u]);
@@ -2160,8 +2183,9 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     HIP_TRY(hipStreamSynchronize(stream));
 
     if (stats) {
-        unsigned long long h[ST_COUNT];
-        HIP_TRY(hipMemcpy(h, g_lib.stats, sizeof h, hipMemcpyDeviceToHost));
+        unsigned long long copies[STAT_COPIES * ST_COUNT], h[ST_COUNT] = {};
+        HIP_TRY(hipMemcpy(copies, g_lib.stats, sizeof copies, hipMemcpyDeviceToHost));
+        for (int c = 0; c < STAT_COPIES; ++c) for (int k = 0; k < ST_COUNT; ++k) h[k] += copies[c * ST_COUNT + k];
         std::memset(stats, 0, sizeof *stats);
         // samples inside the rectangle, from the tile geometry; the bounding box culled those that are not live
         unsigned long long inside = 0;
@@ -2301,7 +2325,7 @@ int rt_init(int device) {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&g_lib.stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_lib.counts), 64 * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_lib.stats), ST_COUNT * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_lib.stats), STAT_COPIES * ST_COUNT * sizeof(unsigned long long)));
     g_lib.device = device;
     g_lib.ready = true;
     return 0;
