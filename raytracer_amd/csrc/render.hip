@@ -2,16 +2,24 @@
 // C ABI around it (include/rt_amd.h).
 //
 // One image is traced as a stream of ray batches instead of one recursive call per sample:
-//   k_primary  : camera rays + scene-box cull            (ray_tracing.cpp:460-473, :265-297, render_work_queue.cpp:37-49)
-//   k_closest  : brute-force closest hit over every primitive, kind choice, normal,
-//                ambient + emission                       (ray_tracing.cpp:484-686)
-//   k_shadow   : brute-force any-hit toward one light     (ray_tracing.cpp:347-458)
-//   k_shade    : Blinn-Phong per unblocked light, attenuation, reflection (ray_tracing.cpp:687-728)
-//   k_resolve  : 16-sample average and 8-bit conversion   (render_work_queue.cpp:51-55)
-// Rays that are still alive are kept in compacted index lists, so the two scan kernels,
-// where all the time goes, always run with full wavefronts.  In the scan kernels a lane
-// owns RAYS_PER_LANE rays, a workgroup walks the primitive list in tiles staged in LDS,
-// and every lane reads the same primitive record (an LDS broadcast).
+//   k_primary        : camera rays + scene-box cull       (ray_tracing.cpp:460-473, :265-297, render_work_queue.cpp:37-49)
+//   k_closest_scan,
+//   k_closest_sph/ell: closest hit per primitive kind     (ray_tracing.cpp:484-608)
+//   k_hit            : kind choice, hit point, normal, ambient + emission (ray_tracing.cpp:610-686)
+//   k_shadow_scan,
+//   k_shadow_sph/ell : any-hit toward one light           (ray_tracing.cpp:347-458)
+//   k_shade          : Blinn-Phong per unblocked light, attenuation, reflection (ray_tracing.cpp:687-728)
+//   k_resolve        : 16-sample average and 8-bit conversion (render_work_queue.cpp:51-55)
+// Rays that are still alive are kept in index lists compacted in order (k_scan_flags,
+// k_scan_blocks, k_fill_list), so every launch runs with full wavefronts of rays that are
+// neighbours in the image.
+// Two ways through the primitive lists give the same bytes:
+//   brute force (RT_FLAG_NO_FILTER): every ray against every primitive through the literal
+//     test of the reference, records staged in LDS tiles and read as broadcasts;
+//   default: conservative bounds (cones, spheres) over a three-level hierarchy of the
+//     primitives decide almost every pair; what is left goes through the same literal test.
+//     The closest hit is an atomicMin over (distance, scan index) keys, so the order of
+//     the visits does not matter.
 //
 // Arithmetic contract: IEEE binary32, round to nearest, denormals kept, no contraction
 // (-ffp-contract=off); the fused multiply-adds the reference executes are explicit
@@ -1013,10 +1021,10 @@ __global__ void __launch_bounds__(BLOCK) k_fill_list(State st, const uint32_t* _
 // ------------------------------------------------------------------------------------------
 // closest-hit scans: one kernel per primitive kind, then k_hit
 // ------------------------------------------------------------------------------------------
-// Each kind has its own kernel so that the triangle scan, where the time goes, is compiled with
-// only the registers its own loop needs.  A scan leaves (distance, scan index) of its kind in the
-// ray's state; k_hit combines the three.  The result slots reuse the arrays that k_hit itself
-// fills afterwards (hit point and normal), which nothing reads in between.
+// Each kind has its own launch.  Triangles and ellipsoids leave their closest hit as a 64-bit key
+// (pack_hit) in st.key / st.key_ell; the brute-force sphere scan leaves (distance, scan index) in
+// two arrays that k_hit itself fills afterwards (hit point and normal) and nothing reads in
+// between.  k_hit combines the three.
 DEV float* closest_t_slot(const State& st, int kind) { return kind == 0 ? st.px : (kind == 1 ? st.pz : st.ny); }
 DEV uint32_t* closest_k_slot(const State& st, int kind) {
     return reinterpret_cast<uint32_t*>(kind == 0 ? st.py : (kind == 1 ? st.nx : st.nz));
@@ -1121,13 +1129,19 @@ DEV float pretests_then_full(const DevScene& sc, uint32_t pos, V3 o, V3 d, uint3
     return hit_triangle(o, d, rec[0], rec[1], rec[2], rec[3].x);
 }
 
-// MODE 0: every triangle through the full test (RT_FLAG_NO_FILTER);
-// 2: cone pre-test for rays from the eye (bounce 0); 3: bounding-sphere pre-test for rays with their own origin.
-// In modes 2 and 3 a lane keeps only direction (and moment) of its R rays; pairs the pre-test
-// keeps are queued and drained through pretests_then_full.  Result: st.key[slot].
+// Closest hit of every live ray over the primitives of kind PRIM (0 triangles, 1 ellipsoids).
+// MODE 0: brute force, every triangle through the full test (RT_FLAG_NO_FILTER): tiles of records
+// staged in LDS, broadcast reads, per-lane running minimum.
+// MODE 2 (rays from the eye, cone records) and 3 (rays with their own origin, sphere records):
+// the wave walks the bounding hierarchy of the kind.  Top nodes are tested one per lane against
+// the bound of the whole wave (packet test), then per ray; (ray, node) pairs go through three
+// per-wave queues in LDS (top node -> cluster -> leaf), each walked one pair per lane, and the
+// (ray, leaf) pairs that remain through the full test of the kind (for triangles after the
+// two-stage pre-test).  Result: st.key[slot] / st.key_ell[slot], by atomicMin.
 template <int R, int MODE, int PRIM>
 __global__ void __launch_bounds__(BLOCK) k_closest_scan(DevScene sc, State st, uint32_t bounce) {
     static_assert(MODE != 0 || PRIM == 0, "the full-test mode of this kernel is for triangles");
+    static_assert(64 * R <= PUSH_MAX && 64 * R <= 256, "a queue entry has 8 bits for the ray, a push adds at most PUSH_MAX entries");
     const Hierarchy& h = PRIM == 0 ? sc.th : sc.eh;
     constexpr int WORDS = 4;
     __shared__ float4 lds[MODE == 0 ? TILE_PRIMS * WORDS : 1];   // record tiles, full-test mode only
@@ -1534,13 +1548,16 @@ DEV ShadowRay make_shadow_ray(const State& st, uint32_t slot, bool point, V3 lv)
     return s;
 }
 
-// MODE 0: full test only; 2: cone pre-test (point lights only: lights first_light.. are point
-// lights, their cone records start at sc.cone_light); 3: bounding-sphere pre-test for rays with their own
-// origin (any light).  Queues as in k_closest_scan; a drained pair that blocks sets the
-// owner's bit in LDS, which the owner picks up after the drain.
+// Any-hit of every hit point toward light first_light + blockIdx.y over the primitives of kind PRIM.
+// MODE 0: brute force over the triangles; 2: cone records of that point light (lights
+// first_light.. are point lights then); 3: sphere records (any light; used for the directional
+// one).  Queues as in k_closest_scan; a (ray, leaf) pair that blocks sets the ray's bit in LDS,
+// which the lane that holds the ray picks up after the drain; the wave stops when all its rays
+// are blocked.
 template <int R, int MODE, int PRIM>
 __global__ void __launch_bounds__(BLOCK) k_shadow_scan(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
     static_assert(MODE != 0 || PRIM == 0, "the full-test mode of this kernel is for triangles");
+    static_assert(64 * R <= PUSH_MAX && 64 * R <= 256, "a queue entry has 8 bits for the ray, a push adds at most PUSH_MAX entries");
     const Hierarchy& h = PRIM == 0 ? sc.th : sc.eh;
     constexpr int WORDS = 4;
     __shared__ float4 lds[MODE == 0 ? TILE_PRIMS * WORDS : 1];   // record tiles, full-test mode only
@@ -1954,9 +1971,9 @@ Library g_lib;
 #ifndef RT_R_SHADOW_STRIP
 #define RT_R_SHADOW_STRIP 2
 #endif
-constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;   // full-test, sphere and ellipsoid scans
-// The pre-test scans execute so few instructions per test that the LDS broadcast reads of the
-// records (4 LDS cycles per float4 per wave) only stay hidden with several rays per lane.
+constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;   // brute-force scans
+// Rays per lane of the hierarchy scans.  A wave's life is a chain of dependent L2 round trips whose
+// length grows with its number of rays, and the launch ends with its slowest wave: 2 beat 4 (and 1).
 constexpr int R_CONE = RT_R_CONE, R_STRIP = RT_R_STRIP, R_SHADOW_CONE = RT_R_SHADOW_CONE, R_SHADOW_STRIP = RT_R_SHADOW_STRIP;
 constexpr uint32_t DEFAULT_CHUNK_TILES = 32768;   // 134 M samples, 14.5 GB of ray state: a 3840x2160 frame in one chunk (long launches hide the tail of the slowest waves)
 constexpr uint32_t MAX_BOUNCES = 62;
