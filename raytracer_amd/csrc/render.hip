@@ -1114,16 +1114,19 @@ DEV void push_bits(uint32_t* q, uint32_t& count, uint32_t bits, uint32_t n_bits,
     }
 }
 
-// two-stage pre-test and, if it keeps the ray, the full test; FLT_MAX otherwise.  `pos` is the
-// triangle's position in cluster order; its pre-test record carries the scan index k, so that the
-// full-test record is only looked up for the pairs that need it.
-DEV float pretests_then_full(const DevScene& sc, uint32_t pos, V3 o, V3 d, uint32_t& n_full, uint32_t& k) {
+// The pre-test record of the triangle at position `pos` of the cluster order; it carries the scan
+// index k in a spare word, so that the full-test record is only looked up for the pairs that need it.
+struct TriPair { float4 f0, f1, f2, f3; };
+DEV TriPair load_tri_pair(const DevScene& sc, uint32_t pos) {
     const float4* __restrict__ f = sc.trif_pos + static_cast<size_t>(pos) * 4;
-    const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
-    k = __float_as_uint(f2.w);
+    return TriPair{f[0], f[1], f[2], f[3]};
+}
+// two-stage pre-test and, if it keeps the ray, the full test; FLT_MAX otherwise
+DEV float pretests_then_full(const DevScene& sc, const TriPair& f, V3 o, V3 d, uint32_t& n_full, uint32_t& k) {
+    k = __float_as_uint(f.f2.w);
     Pre pre;
     const float o_max = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
-    if (!(pretest_stage1(o, d, o_max, f0, f1, f2, pre) && pretest_stage2(pre, f3))) return FLT_MAX;
+    if (!(pretest_stage1(o, d, o_max, f.f0, f.f1, f.f2, pre) && pretest_stage2(pre, f.f3))) return FLT_MAX;
     const float4* __restrict__ rec = sc.tri + static_cast<size_t>(k) * 4;
     n_full++;
     return hit_triangle(o, d, rec[0], rec[1], rec[2], rec[3].x);
@@ -1230,16 +1233,22 @@ __global__ void __launch_bounds__(BLOCK) k_closest_scan(DevScene sc, State st, u
     // (ray, triangle) pairs: two-stage pre-test and full test, one pair per lane
     auto drain2 = [&]() {
         wave_sync();
-        for (uint32_t i = lane; i < q2_count; i += 64) {
-            const uint32_t e = q2[i];
-            const uint32_t s = wave_slots[e >> 24];
-            const V3 o{st.ox[s], st.oy[s], st.oz[s]};
-            const V3 dd{st.dx[s], st.dy[s], st.dz[s]};
-            if (PRIM == 0) {
+        if (PRIM == 0) {
+            for (uint32_t i = lane; i < q2_count; i += 64) {
+                const uint32_t e = q2[i];
+                const uint32_t s = wave_slots[e >> 24];
+                const V3 o{st.ox[s], st.oy[s], st.oz[s]};
+                const V3 dd{st.dx[s], st.dy[s], st.dz[s]};
                 uint32_t k;
-                const float t = pretests_then_full(sc, e & NODE_MASK, o, dd, n_full, k);
+                const float t = pretests_then_full(sc, load_tri_pair(sc, e & NODE_MASK), o, dd, n_full, k);
                 if (t < FLT_MAX) atomicMin(&st.key[s], pack_hit(t, k));
-            } else {
+            }
+        } else {
+            for (uint32_t i = lane; i < q2_count; i += 64) {
+                const uint32_t e = q2[i];
+                const uint32_t s = wave_slots[e >> 24];
+                const V3 o{st.ox[s], st.oy[s], st.oz[s]};
+                const V3 dd{st.dx[s], st.dy[s], st.dz[s]};
                 const uint32_t k = h.k_of[e & NODE_MASK];
                 const float4* __restrict__ rec = sc.ell + static_cast<size_t>(k) * 6;
                 const float t = hit_ellipsoid(o, dd, rec[0], rec[1], rec[2], rec[3], rec[4], rec[5]);
@@ -1631,22 +1640,25 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_scan(DevScene sc, State st, ui
     // (ray, triangle) pairs: two-stage pre-test and full test, one pair per lane; a pair that blocks sets its ray's bit
     auto drain2 = [&]() {
         wave_sync();
-        for (uint32_t i = lane; i < q2_count; i += 64) {
-            const uint32_t e = q2[i];
-            const uint32_t ray = e >> 24;
-            const ShadowRay s = make_shadow_ray(st, wave_slots[ray], point, lv);
-            bool blocks;
-            if (PRIM == 0) {
+        if (PRIM == 0) {
+            for (uint32_t i = lane; i < q2_count; i += 64) {
+                const uint32_t e = q2[i];
+                const uint32_t ray = e >> 24;
+                const ShadowRay s = make_shadow_ray(st, wave_slots[ray], point, lv);
                 uint32_t k;
-                blocks = pretests_then_full(sc, e & NODE_MASK, s.o, s.d, n_full, k) < s.limit;
-            } else {
+                if (pretests_then_full(sc, load_tri_pair(sc, e & NODE_MASK), s.o, s.d, n_full, k) < s.limit) atomicOr(&lds_blocked[wave * 64u + (ray & 63u)], 1u << (ray >> 6));
+            }
+        } else {
+            for (uint32_t i = lane; i < q2_count; i += 64) {
+                const uint32_t e = q2[i];
+                const uint32_t ray = e >> 24;
+                const ShadowRay s = make_shadow_ray(st, wave_slots[ray], point, lv);
                 const uint32_t k = h.k_of[e & NODE_MASK];
                 const float4* __restrict__ rec = sc.ell + static_cast<size_t>(k) * 6;
                 const V3 l2 = point ? xyz(sc.ell_light[static_cast<size_t>(light - sc.has_directional) * sc.n_ell + k]) : V3{0.0f, 0.0f, 0.0f};
-                blocks = ellipsoid_blocks(s.o, s.d, rec[0], rec[1], rec[2], point, l2);
                 n_full++;
+                if (ellipsoid_blocks(s.o, s.d, rec[0], rec[1], rec[2], point, l2)) atomicOr(&lds_blocked[wave * 64u + (ray & 63u)], 1u << (ray >> 6));
             }
-            if (blocks) atomicOr(&lds_blocked[wave * 64u + (ray & 63u)], 1u << (ray >> 6));
         }
         wave_sync();
         n_queued += q2_count;
@@ -1959,22 +1971,12 @@ Library g_lib;
 #ifndef RT_RAYS_PER_LANE
 #define RT_RAYS_PER_LANE 2
 #endif
-#ifndef RT_R_CONE
-#define RT_R_CONE 2
-#endif
-#ifndef RT_R_STRIP
-#define RT_R_STRIP 2
-#endif
-#ifndef RT_R_SHADOW_CONE
-#define RT_R_SHADOW_CONE 2
-#endif
-#ifndef RT_R_SHADOW_STRIP
-#define RT_R_SHADOW_STRIP 2
-#endif
 constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;   // brute-force scans
 // Rays per lane of the hierarchy scans.  A wave's life is a chain of dependent L2 round trips whose
-// length grows with its number of rays, and the launch ends with its slowest wave: 2 beat 4 (and 1).
-constexpr int R_CONE = RT_R_CONE, R_STRIP = RT_R_STRIP, R_SHADOW_CONE = RT_R_SHADOW_CONE, R_SHADOW_STRIP = RT_R_SHADOW_STRIP;
+// length grows with its number of rays, and a launch ends with its slowest wave: one ray per lane
+// is best while the top level is short (scene7: 391 top nodes).  Walking a long top level once per
+// wave costs more than that, so big scenes (the synthetic one: 3907 top nodes) take two.
+constexpr uint32_t TOPS_FOR_TWO_RAYS = 1024;
 constexpr uint32_t DEFAULT_CHUNK_TILES = 32768;   // 134 M samples, 14.5 GB of ray state: a 3840x2160 frame in one chunk (long launches hide the tail of the slowest waves)
 constexpr uint32_t MAX_BOUNCES = 62;
 
@@ -2143,18 +2145,39 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
             return blocks > SEG_TARGET ? blocks : SEG_TARGET;
         };
         const uint32_t ray_blocks = n_samples / BLOCK;
+        // hierarchy scans of kind `prim`, with one or two rays per lane (TOPS_FOR_TWO_RAYS)
+        auto closest_scan = [&](int prim, bool eye_rays, uint32_t b) {
+            const bool two = (prim == 0 ? sc.th : sc.eh).n_tops > TOPS_FOR_TWO_RAYS;
+            const dim3 grid(blocks_for(two ? 2 : 1));
+            if (prim == 0) {
+                if (eye_rays) { if (two) hipLaunchKernelGGL((k_closest_scan<2, 2, 0>), grid, dim3(BLOCK), 0, stream, sc, st, b); else hipLaunchKernelGGL((k_closest_scan<1, 2, 0>), grid, dim3(BLOCK), 0, stream, sc, st, b); }
+                else { if (two) hipLaunchKernelGGL((k_closest_scan<2, 3, 0>), grid, dim3(BLOCK), 0, stream, sc, st, b); else hipLaunchKernelGGL((k_closest_scan<1, 3, 0>), grid, dim3(BLOCK), 0, stream, sc, st, b); }
+            } else {
+                if (eye_rays) { if (two) hipLaunchKernelGGL((k_closest_scan<2, 2, 1>), grid, dim3(BLOCK), 0, stream, sc, st, b); else hipLaunchKernelGGL((k_closest_scan<1, 2, 1>), grid, dim3(BLOCK), 0, stream, sc, st, b); }
+                else { if (two) hipLaunchKernelGGL((k_closest_scan<2, 3, 1>), grid, dim3(BLOCK), 0, stream, sc, st, b); else hipLaunchKernelGGL((k_closest_scan<1, 3, 1>), grid, dim3(BLOCK), 0, stream, sc, st, b); }
+            }
+        };
+        auto shadow_scan = [&](int prim, bool point_lights, uint32_t n, uint32_t b, uint32_t first_light, uint32_t group_first) {
+            const bool two = (prim == 0 ? sc.th : sc.eh).n_tops > TOPS_FOR_TWO_RAYS;
+            const dim3 grid(blocks_for(two ? 2 : 1), n);
+            if (prim == 0) {
+                if (point_lights) { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 2, 0>), grid, dim3(BLOCK), 0, stream, sc, st, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 2, 0>), grid, dim3(BLOCK), 0, stream, sc, st, b, first_light, group_first); }
+                else { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 3, 0>), grid, dim3(BLOCK), 0, stream, sc, st, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 3, 0>), grid, dim3(BLOCK), 0, stream, sc, st, b, first_light, group_first); }
+            } else {
+                if (point_lights) { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 2, 1>), grid, dim3(BLOCK), 0, stream, sc, st, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 2, 1>), grid, dim3(BLOCK), 0, stream, sc, st, b, first_light, group_first); }
+                else { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 3, 1>), grid, dim3(BLOCK), 0, stream, sc, st, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 3, 1>), grid, dim3(BLOCK), 0, stream, sc, st, b, first_light, group_first); }
+            }
+        };
         for (uint32_t b = 0; b < depth; ++b) {
             timed(timer, 0, [&] {
                 if (sc.n_tri) {
                     if (!filter) hipLaunchKernelGGL((k_closest_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-                    else if (b == 0) hipLaunchKernelGGL((k_closest_scan<R_CONE, 2, 0>), dim3(blocks_for(R_CONE)), dim3(BLOCK), 0, stream, sc, st, b);
-                    else hipLaunchKernelGGL((k_closest_scan<R_STRIP, 3, 0>), dim3(blocks_for(R_STRIP)), dim3(BLOCK), 0, stream, sc, st, b);
+                    else closest_scan(0, b == 0, b);
                 }
                 if (sc.n_sph) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
                 if (sc.n_ell) {
                     if (!filter) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-                    else if (b == 0) hipLaunchKernelGGL((k_closest_scan<R_CONE, 2, 1>), dim3(blocks_for(R_CONE)), dim3(BLOCK), 0, stream, sc, st, b);
-                    else hipLaunchKernelGGL((k_closest_scan<R_STRIP, 3, 1>), dim3(blocks_for(R_STRIP)), dim3(BLOCK), 0, stream, sc, st, b);
+                    else closest_scan(1, b == 0, b);
                 }
             });
             hipLaunchKernelGGL(k_hit, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, st, b);
@@ -2175,16 +2198,16 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                         if (sc.n_tri) {
                             if (!filter) hipLaunchKernelGGL((k_shadow_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
                             else {
-                                if (n_dir) hipLaunchKernelGGL((k_shadow_scan<R_SHADOW_STRIP, 3, 0>), dim3(blocks_for(R_SHADOW_STRIP), 1), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
-                                if (n_pt) hipLaunchKernelGGL((k_shadow_scan<R_SHADOW_CONE, 2, 0>), dim3(blocks_for(R_SHADOW_CONE), n_pt), dim3(BLOCK), 0, stream, sc, st, b, l0 + n_dir, l0);
+                                if (n_dir) shadow_scan(0, false, 1, b, l0, l0);
+                                if (n_pt) shadow_scan(0, true, n_pt, b, l0 + n_dir, l0);
                             }
                         }
                         if (sc.n_sph) hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
                         if (sc.n_ell) {
                             if (!filter) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
                             else {
-                                if (n_dir) hipLaunchKernelGGL((k_shadow_scan<R_SHADOW_STRIP, 3, 1>), dim3(blocks_for(R_SHADOW_STRIP), 1), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
-                                if (n_pt) hipLaunchKernelGGL((k_shadow_scan<R_SHADOW_CONE, 2, 1>), dim3(blocks_for(R_SHADOW_CONE), n_pt), dim3(BLOCK), 0, stream, sc, st, b, l0 + n_dir, l0);
+                                if (n_dir) shadow_scan(1, false, 1, b, l0, l0);
+                                if (n_pt) shadow_scan(1, true, n_pt, b, l0 + n_dir, l0);
                             }
                         }
                     });
