@@ -127,12 +127,14 @@ struct Frame {
 
 // Per-sample state of one chunk, structure of arrays, indexed by the sample's slot.
 struct State {
-    float *ox, *oy, *oz, *dx, *dy, *dz;   // current ray
+    float *ox, *oy, *oz, *dx, *dy, *dz;   // ray of the current bounce
+    float *nox, *noy, *noz, *ndx, *ndy, *ndz;   // ray of the next bounce (the host swaps the two sets per bounce)
     float *wr, *wg, *wb;                  // colour weighting
     float *cr, *cg, *cb;                  // accumulated colour
     float *px, *py, *pz, *nx, *ny, *nz;   // hit point and unit normal of the current bounce
     unsigned long long* key;              // closest triangle of the current bounce, see pack_hit
     unsigned long long* key_ell;          // closest ellipsoid of the current bounce, same format
+    unsigned long long* key_sph;          // closest sphere of the current bounce, same format
     uint32_t* hit_id;                     // RT_ID_MAKE(kind, original index) of the current bounce
     uint32_t* blocked;                    // bit l: light l of the current group is blocked
     uint32_t* list[2];                    // compacted slots of live rays, ping-pong
@@ -940,7 +942,7 @@ __global__ void __launch_bounds__(BLOCK) k_primary(Frame f, DevScene sc, State s
         st.dx[s] = d.x; st.dy[s] = d.y; st.dz[s] = d.z;
         st.wr[s] = 1.0f; st.wg[s] = 1.0f; st.wb[s] = 1.0f;
     }
-    if (live) { st.key[s] = NO_HIT_KEY; st.key_ell[s] = NO_HIT_KEY; }
+    if (live) { st.key[s] = NO_HIT_KEY; st.key_ell[s] = NO_HIT_KEY; st.key_sph[s] = NO_HIT_KEY; }
     if (st.primary_id) st.primary_id[s] = live ? RT_ID_MISS : RT_ID_CULLED;
     const unsigned long long live_mask = __ballot(live);    // list 0 is built from these by k_scan_flags + k_fill_list
     if ((threadIdx.x & 63u) == 0) st.flag_bits[blockIdx.x * 4u + (threadIdx.x >> 6)] = live_mask;
@@ -1021,14 +1023,8 @@ __global__ void __launch_bounds__(BLOCK) k_fill_list(State st, const uint32_t* _
 // ------------------------------------------------------------------------------------------
 // closest-hit scans: one kernel per primitive kind, then k_hit
 // ------------------------------------------------------------------------------------------
-// Each kind has its own launch.  Triangles and ellipsoids leave their closest hit as a 64-bit key
-// (pack_hit) in st.key / st.key_ell; the brute-force sphere scan leaves (distance, scan index) in
-// two arrays that k_hit itself fills afterwards (hit point and normal) and nothing reads in
-// between.  k_hit combines the three.
-DEV float* closest_t_slot(const State& st, int kind) { return kind == 0 ? st.px : (kind == 1 ? st.pz : st.ny); }
-DEV uint32_t* closest_k_slot(const State& st, int kind) {
-    return reinterpret_cast<uint32_t*>(kind == 0 ? st.py : (kind == 1 ? st.nx : st.nz));
-}
+// Each kind has its own launch and leaves its closest hit as a 64-bit key (pack_hit) in
+// st.key / st.key_sph / st.key_ell; k_hit combines the three.
 
 // LDS staging: a tile of `count` records of WORDS float4 each is copied by the whole
 // workgroup; `lds` must hold TILE_PRIMS * WORDS float4.
@@ -1357,10 +1353,8 @@ __global__ void __launch_bounds__(BLOCK) k_closest_sph(DevScene sc, State st, ui
             }
         }
     }
-    float* out_t = closest_t_slot(st, 1);
-    uint32_t* out_k = closest_k_slot(st, 1);
 #pragma unroll
-    for (int r = 0; r < R; ++r) if (valid[r]) { out_t[slot[r]] = best_t[r]; out_k[slot[r]] = best_k[r]; }
+    for (int r = 0; r < R; ++r) if (valid[r]) st.key_sph[slot[r]] = best_k[r] == 0xFFFFFFFFu ? NO_HIT_KEY : pack_hit(best_t[r], best_k[r]);
 }
 
 template <int R>
@@ -1412,7 +1406,11 @@ __global__ void __launch_bounds__(BLOCK) k_hit(DevScene sc, State st, uint32_t b
         k_kind[0] = static_cast<uint32_t>(key & 0xFFFFFFFFull);
         if (k_kind[0] != 0xFFFFFFFFu) t_kind[0] = __uint_as_float(static_cast<uint32_t>(key >> 32));
     }
-    if (sc.n_sph) { t_kind[1] = closest_t_slot(st, 1)[s]; k_kind[1] = closest_k_slot(st, 1)[s]; }
+    if (sc.n_sph) {
+        const unsigned long long key = st.key_sph[s];
+        k_kind[1] = static_cast<uint32_t>(key & 0xFFFFFFFFull);
+        if (k_kind[1] != 0xFFFFFFFFu) t_kind[1] = __uint_as_float(static_cast<uint32_t>(key >> 32));
+    }
     if (sc.n_ell) {
         const unsigned long long key = st.key_ell[s];
         k_kind[2] = static_cast<uint32_t>(key & 0xFFFFFFFFull);
@@ -1468,11 +1466,18 @@ __global__ void __launch_bounds__(BLOCK) k_hit(DevScene sc, State st, uint32_t b
         st.cb[s] += st.wb[s] * (sc.ambient[2] + e2);
         st.px[s] = p.x; st.py[s] = p.y; st.pz[s] = p.z;
         st.nx[s] = n.x; st.ny[s] = n.y; st.nz[s] = n.z;
+        // the reflected ray (ray_tracing.cpp:685, :728; the direction is not renormalised).  It does not depend on the
+        // shadow rays, so the next bounce's closest-hit scan can run beside this bounce's shadow scans.
+        const V3 above = add(p, scale(2.0f * TOL, n));
+        st.nox[s] = above.x; st.noy[s] = above.y; st.noz[s] = above.z;
+        const V3 refl = sub(d, scale(2.0f * sdot(d, n), n));
+        st.ndx[s] = refl.x; st.ndy[s] = refl.y; st.ndz[s] = refl.z;
         const uint32_t id = RT_ID_MAKE(static_cast<uint32_t>(kind), index);
         st.hit_id[s] = id;
         st.blocked[s] = 0u;
         st.key[s] = NO_HIT_KEY;      // for the next bounce's triangle scan
         st.key_ell[s] = NO_HIT_KEY;
+        st.key_sph[s] = NO_HIT_KEY;
         if (bounce == 0 && st.primary_id) st.primary_id[s] = id;
     }
     const unsigned long long hit_mask = __ballot(hit);      // the next list is built from these by k_scan_flags + k_fill_list
@@ -1900,10 +1905,6 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, State st, uint32_t
     if (last_group) {
         st.blocked[s] = 0u;
         st.wr[s] = w[0] * m[3]; st.wg[s] = w[1] * m[4]; st.wb[s] = w[2] * m[5];   // ray_tracing.cpp:726
-        const V3 above = add(p, scale(2.0f * TOL, n));
-        st.ox[s] = above.x; st.oy[s] = above.y; st.oz[s] = above.z;
-        const V3 refl = sub(d, scale(2.0f * sdot(d, n), n));              // ray_tracing.cpp:728, not renormalised
-        st.dx[s] = refl.x; st.dy[s] = refl.y; st.dz[s] = refl.z;
     } else {
         st.blocked[s] = 0u;
     }
@@ -1959,6 +1960,8 @@ struct Library {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;      // the next bounce's closest-hit scans run here, beside the shadow scans
+    std::vector<hipEvent_t> sync_events;    // fork / join between the two streams (no timing)
     // per-chunk sample state, grown on demand
     void* state_mem = nullptr;
     size_t state_samples = 0;
@@ -1977,7 +1980,7 @@ constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;   // brute-force scans
 // is best while the top level is short (scene7: 391 top nodes).  Walking a long top level once per
 // wave costs more than that, so big scenes (the synthetic one: 3907 top nodes) take two.
 constexpr uint32_t TOPS_FOR_TWO_RAYS = 1024;
-constexpr uint32_t DEFAULT_CHUNK_TILES = 32768;   // 134 M samples, 14.5 GB of ray state: a 3840x2160 frame in one chunk (long launches hide the tail of the slowest waves)
+constexpr uint32_t DEFAULT_CHUNK_TILES = 32768;   // 134 M samples, 18.8 GB of ray state: a 3840x2160 frame in one chunk (long launches hide the tail of the slowest waves)
 constexpr uint32_t MAX_BOUNCES = 62;
 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
@@ -2016,9 +2019,9 @@ namespace {
 int ensure_state(size_t samples) {
     if (g_lib.state_samples >= samples) return 0;
     if (g_lib.state_mem) { HIP_TRY(hipFree(g_lib.state_mem)); g_lib.state_mem = nullptr; g_lib.state_samples = 0; }
-    // 18 float arrays + hit_id + blocked + 2 lists + primary ids + two 64-bit keys = 27 words per sample
+    // 24 float arrays + hit_id + blocked + 2 lists + primary ids + three 64-bit keys = 35 words per sample
     // + per 256 samples: 4 wave ballots and one offset (ordered compaction)
-    HIP_TRY(hipMalloc(&g_lib.state_mem, samples * 27 * sizeof(float) + samples / BLOCK * 40 + SCAN_THREADS * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&g_lib.state_mem, samples * 35 * sizeof(float) + samples / BLOCK * 40 + SCAN_THREADS * sizeof(uint32_t)));
     g_lib.state_samples = samples;
     return 0;
 }
@@ -2027,7 +2030,7 @@ State make_state(size_t samples, bool want_ids) {
     State st;
     float* f = static_cast<float*>(g_lib.state_mem);
     float** fields[] = {&st.ox, &st.oy, &st.oz, &st.dx, &st.dy, &st.dz, &st.wr, &st.wg, &st.wb, &st.cr, &st.cg, &st.cb,
-                        &st.px, &st.py, &st.pz, &st.nx, &st.ny, &st.nz};
+                        &st.px, &st.py, &st.pz, &st.nx, &st.ny, &st.nz, &st.nox, &st.noy, &st.noz, &st.ndx, &st.ndy, &st.ndz};
     size_t k = 0;
     for (float** field : fields) *field = f + samples * k++;
     uint32_t* u = reinterpret_cast<uint32_t*>(f + samples * k);
@@ -2035,7 +2038,8 @@ State make_state(size_t samples, bool want_ids) {
     st.primary_id = want_ids ? u + 4 * samples : nullptr;
     st.key = reinterpret_cast<unsigned long long*>(u + 5 * samples);   // 8-byte aligned: samples is a multiple of 4096
     st.key_ell = st.key + samples;
-    st.flag_bits = st.key_ell + samples;                               // 16-byte aligned likewise
+    st.key_sph = st.key_ell + samples;
+    st.flag_bits = st.key_sph + samples;                               // 16-byte aligned likewise
     st.wg_offset = reinterpret_cast<uint32_t*>(st.flag_bits + samples / BLOCK * 4);
     st.scan_block = st.wg_offset + samples / BLOCK + samples / BLOCK % 2;   // after the offsets (8 bytes of the 40 per workgroup are spare)
     st.counts = g_lib.counts;
@@ -2058,13 +2062,23 @@ struct Timer {
 };
 
 template <typename Launch>
-void timed(Timer* timer, int family, Launch&& launch) {
+void timed(Timer* timer, int family, hipStream_t stream, Launch&& launch) {
     if (!timer) { launch(); return; }
     hipEvent_t a = timer->take(), b = timer->take();
-    if (a) (void)hipEventRecord(a, g_lib.stream);
+    if (a) (void)hipEventRecord(a, stream);
     launch();
-    if (b) (void)hipEventRecord(b, g_lib.stream);
+    if (b) (void)hipEventRecord(b, stream);
     if (a && b) timer->spans[family].push_back({a, b});
+}
+
+// event number i of the fork/join pool
+hipEvent_t sync_event(size_t i) {
+    while (g_lib.sync_events.size() <= i) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        g_lib.sync_events.push_back(e);
+    }
+    return g_lib.sync_events[i];
 }
 
 int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_render_params* prm, uint8_t* tiles_dev,
@@ -2145,75 +2159,105 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
             return blocks > SEG_TARGET ? blocks : SEG_TARGET;
         };
         const uint32_t ray_blocks = n_samples / BLOCK;
-        // hierarchy scans of kind `prim`, with one or two rays per lane (TOPS_FOR_TWO_RAYS)
-        auto closest_scan = [&](int prim, bool eye_rays, uint32_t b) {
-            const bool two = (prim == 0 ? sc.th : sc.eh).n_tops > TOPS_FOR_TWO_RAYS;
-            const dim3 grid(blocks_for(two ? 2 : 1));
-            if (prim == 0) {
-                if (eye_rays) { if (two) hipLaunchKernelGGL((k_closest_scan<2, 2, 0>), grid, dim3(BLOCK), 0, stream, sc, st, b); else hipLaunchKernelGGL((k_closest_scan<1, 2, 0>), grid, dim3(BLOCK), 0, stream, sc, st, b); }
-                else { if (two) hipLaunchKernelGGL((k_closest_scan<2, 3, 0>), grid, dim3(BLOCK), 0, stream, sc, st, b); else hipLaunchKernelGGL((k_closest_scan<1, 3, 0>), grid, dim3(BLOCK), 0, stream, sc, st, b); }
-            } else {
-                if (eye_rays) { if (two) hipLaunchKernelGGL((k_closest_scan<2, 2, 1>), grid, dim3(BLOCK), 0, stream, sc, st, b); else hipLaunchKernelGGL((k_closest_scan<1, 2, 1>), grid, dim3(BLOCK), 0, stream, sc, st, b); }
-                else { if (two) hipLaunchKernelGGL((k_closest_scan<2, 3, 1>), grid, dim3(BLOCK), 0, stream, sc, st, b); else hipLaunchKernelGGL((k_closest_scan<1, 3, 1>), grid, dim3(BLOCK), 0, stream, sc, st, b); }
+        // state as bounce b sees it: the two ray sets swap roles every bounce
+        auto state_of = [&](uint32_t b) {
+            State sb = st;
+            if (b & 1u) {
+                std::swap(sb.ox, sb.nox); std::swap(sb.oy, sb.noy); std::swap(sb.oz, sb.noz);
+                std::swap(sb.dx, sb.ndx); std::swap(sb.dy, sb.ndy); std::swap(sb.dz, sb.ndz);
             }
+            return sb;
         };
-        auto shadow_scan = [&](int prim, bool point_lights, uint32_t n, uint32_t b, uint32_t first_light, uint32_t group_first) {
+        // closest-hit scans of bounce b, all kinds, on stream `on`
+        auto closest_scans = [&](uint32_t b, hipStream_t on) {
+            const State sb = state_of(b);
+            auto hierarchy_scan = [&](int prim) {   // one or two rays per lane (TOPS_FOR_TWO_RAYS)
+                const bool two = (prim == 0 ? sc.th : sc.eh).n_tops > TOPS_FOR_TWO_RAYS;
+                const dim3 grid(blocks_for(two ? 2 : 1));
+                const bool eye_rays = b == 0;
+                if (prim == 0) {
+                    if (eye_rays) { if (two) hipLaunchKernelGGL((k_closest_scan<2, 2, 0>), grid, dim3(BLOCK), 0, on, sc, sb, b); else hipLaunchKernelGGL((k_closest_scan<1, 2, 0>), grid, dim3(BLOCK), 0, on, sc, sb, b); }
+                    else { if (two) hipLaunchKernelGGL((k_closest_scan<2, 3, 0>), grid, dim3(BLOCK), 0, on, sc, sb, b); else hipLaunchKernelGGL((k_closest_scan<1, 3, 0>), grid, dim3(BLOCK), 0, on, sc, sb, b); }
+                } else {
+                    if (eye_rays) { if (two) hipLaunchKernelGGL((k_closest_scan<2, 2, 1>), grid, dim3(BLOCK), 0, on, sc, sb, b); else hipLaunchKernelGGL((k_closest_scan<1, 2, 1>), grid, dim3(BLOCK), 0, on, sc, sb, b); }
+                    else { if (two) hipLaunchKernelGGL((k_closest_scan<2, 3, 1>), grid, dim3(BLOCK), 0, on, sc, sb, b); else hipLaunchKernelGGL((k_closest_scan<1, 3, 1>), grid, dim3(BLOCK), 0, on, sc, sb, b); }
+                }
+            };
+            timed(timer, 0, on, [&] {
+                if (sc.n_tri) {
+                    if (!filter) hipLaunchKernelGGL((k_closest_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
+                    else hierarchy_scan(0);
+                }
+                if (sc.n_sph) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
+                if (sc.n_ell) {
+                    if (!filter) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
+                    else hierarchy_scan(1);
+                }
+            });
+        };
+        auto shadow_scan = [&](const State& sb, int prim, bool point_lights, uint32_t n, uint32_t b, uint32_t first_light, uint32_t group_first) {
             const bool two = (prim == 0 ? sc.th : sc.eh).n_tops > TOPS_FOR_TWO_RAYS;
             const dim3 grid(blocks_for(two ? 2 : 1), n);
             if (prim == 0) {
-                if (point_lights) { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 2, 0>), grid, dim3(BLOCK), 0, stream, sc, st, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 2, 0>), grid, dim3(BLOCK), 0, stream, sc, st, b, first_light, group_first); }
-                else { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 3, 0>), grid, dim3(BLOCK), 0, stream, sc, st, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 3, 0>), grid, dim3(BLOCK), 0, stream, sc, st, b, first_light, group_first); }
+                if (point_lights) { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 2, 0>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 2, 0>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, group_first); }
+                else { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 3, 0>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 3, 0>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, group_first); }
             } else {
-                if (point_lights) { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 2, 1>), grid, dim3(BLOCK), 0, stream, sc, st, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 2, 1>), grid, dim3(BLOCK), 0, stream, sc, st, b, first_light, group_first); }
-                else { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 3, 1>), grid, dim3(BLOCK), 0, stream, sc, st, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 3, 1>), grid, dim3(BLOCK), 0, stream, sc, st, b, first_light, group_first); }
+                if (point_lights) { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 2, 1>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 2, 1>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, group_first); }
+                else { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 3, 1>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 3, 1>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, group_first); }
             }
         };
+
+        // Per bounce: closest-hit scans -> k_hit (which also writes the reflected ray) -> list compaction ->
+        // shadow scans + k_shade.  The closest-hit scans of bounce b+1 need only the reflected rays and the
+        // list, so they run on the side stream beside the shadow scans of bounce b (their tails overlap);
+        // k_hit of bounce b+1 waits for both.
+        if (depth) closest_scans(0, stream);
         for (uint32_t b = 0; b < depth; ++b) {
-            timed(timer, 0, [&] {
-                if (sc.n_tri) {
-                    if (!filter) hipLaunchKernelGGL((k_closest_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-                    else closest_scan(0, b == 0, b);
-                }
-                if (sc.n_sph) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-                if (sc.n_ell) {
-                    if (!filter) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-                    else closest_scan(1, b == 0, b);
-                }
-            });
-            hipLaunchKernelGGL(k_hit, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, st, b);
-            hipLaunchKernelGGL(k_scan_flags, dim3(scan_grid), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(st.counts + b), 0u);
-            hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(st.counts + b), 0u, st.counts + b + 1,
+            const State sb = state_of(b);
+            hipLaunchKernelGGL(k_hit, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, sb, b);
+            hipLaunchKernelGGL(k_scan_flags, dim3(scan_grid), dim3(SCAN_THREADS), 0, stream, sb, static_cast<const uint32_t*>(sb.counts + b), 0u);
+            hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_THREADS), 0, stream, sb, static_cast<const uint32_t*>(sb.counts + b), 0u, sb.counts + b + 1,
                                static_cast<int>(ST_CLOSEST_RAYS), static_cast<int>(ST_HITS));
-            hipLaunchKernelGGL(k_fill_list, dim3(ray_blocks), dim3(BLOCK), 0, stream, st, static_cast<const uint32_t*>(st.counts + b), 0u,
-                               static_cast<const uint32_t*>(st.list[b & 1u]), st.list[(b + 1) & 1u]);
+            hipLaunchKernelGGL(k_fill_list, dim3(ray_blocks), dim3(BLOCK), 0, stream, sb, static_cast<const uint32_t*>(sb.counts + b), 0u,
+                               static_cast<const uint32_t*>(sb.list[b & 1u]), sb.list[(b + 1) & 1u]);
+            const bool overlap = b + 1 < depth;
+            hipEvent_t forked = overlap ? sync_event(2 * b) : nullptr, joined = overlap ? sync_event(2 * b + 1) : nullptr;
+            if (overlap && forked && joined) {
+                HIP_TRY(hipEventRecord(forked, stream));
+                HIP_TRY(hipStreamWaitEvent(g_lib.side_stream, forked, 0));
+                closest_scans(b + 1, g_lib.side_stream);
+                HIP_TRY(hipEventRecord(joined, g_lib.side_stream));
+            }
             if (sc.n_lights == 0) {
-                hipLaunchKernelGGL(k_shade, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, st, b, 0u, 0u, 1u);
+                hipLaunchKernelGGL(k_shade, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, sb, b, 0u, 0u, 1u);
             } else {
                 for (uint32_t l0 = 0; l0 < sc.n_lights; l0 += 32) {
                     const uint32_t group = (sc.n_lights - l0 < 32) ? sc.n_lights - l0 : 32;
                     // the directional light, if it is in this group, is light 0; the rest are point lights
                     const uint32_t n_dir = (l0 == 0 && sc.has_directional) ? 1u : 0u;
                     const uint32_t n_pt = group - n_dir;
-                    timed(timer, 1, [&] {
+                    timed(timer, 1, stream, [&] {
                         if (sc.n_tri) {
-                            if (!filter) hipLaunchKernelGGL((k_shadow_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
+                            if (!filter) hipLaunchKernelGGL((k_shadow_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, sb, b, l0, l0);
                             else {
-                                if (n_dir) shadow_scan(0, false, 1, b, l0, l0);
-                                if (n_pt) shadow_scan(0, true, n_pt, b, l0 + n_dir, l0);
+                                if (n_dir) shadow_scan(sb, 0, false, 1, b, l0, l0);
+                                if (n_pt) shadow_scan(sb, 0, true, n_pt, b, l0 + n_dir, l0);
                             }
                         }
-                        if (sc.n_sph) hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
+                        if (sc.n_sph) hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, sb, b, l0, l0);
                         if (sc.n_ell) {
-                            if (!filter) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, st, b, l0, l0);
+                            if (!filter) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, sb, b, l0, l0);
                             else {
-                                if (n_dir) shadow_scan(1, false, 1, b, l0, l0);
-                                if (n_pt) shadow_scan(1, true, n_pt, b, l0 + n_dir, l0);
+                                if (n_dir) shadow_scan(sb, 1, false, 1, b, l0, l0);
+                                if (n_pt) shadow_scan(sb, 1, true, n_pt, b, l0 + n_dir, l0);
                             }
                         }
                     });
-                    hipLaunchKernelGGL(k_shade, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, st, b, l0, group, (l0 + group == sc.n_lights) ? 1u : 0u);
+                    hipLaunchKernelGGL(k_shade, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, sb, b, l0, group, (l0 + group == sc.n_lights) ? 1u : 0u);
                 }
             }
+            if (overlap && forked && joined) HIP_TRY(hipStreamWaitEvent(stream, joined, 0));
+            else if (overlap) closest_scans(b + 1, stream);
         }
         hipLaunchKernelGGL(k_resolve, dim3(n_tiles), dim3(BLOCK), 0, stream, st, first, tiles_dev);
         if (ids_dev) hipLaunchKernelGGL(k_scatter_ids, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, st.primary_id, first, n_samples, f, ids_dev);
@@ -2364,6 +2408,7 @@ int rt_init(int device) {
     if (device < 0 || device >= n) return rt_fail(RT_ERR_ARGUMENT, "rt_init: no such device");
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&g_lib.stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&g_lib.side_stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_lib.counts), 64 * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_lib.stats), STAT_COPIES * ST_COUNT * sizeof(unsigned long long)));
     g_lib.device = device;
