@@ -133,6 +133,7 @@ def main():
     local += [float(sum(s.shadow_tests[k] for s in stats)) for k in range(3)]
     local += [float(sum(s.pair_pretests[k] for s in stats)) for k in range(2)]
     local += [float(sum(s.queued_pairs[k] for s in stats)) for k in range(2)]
+    local += [float(sum(s.executed_flop[k] for s in stats)) for k in range(2)]
     local += [sum(s.closest_ms for s in stats), sum(s.shadow_ms for s in stats), sum(s.device_ms for s in stats)]
     local += [float(sum(s.closest_launches for s in stats)), float(sum(s.shadow_launches for s in stats))]
     acc = torch.tensor(local, dtype=torch.float64, device=device)
@@ -140,9 +141,9 @@ def main():
     if world > 1:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-    tot = dict(zip(fields + ["ct_tri", "ct_sph", "ct_ell", "st_tri", "st_sph", "st_ell", "pp_closest", "pp_shadow", "q_closest", "q_shadow", "closest_ms", "shadow_ms", "device_ms",
+    tot = dict(zip(fields + ["ct_tri", "ct_sph", "ct_ell", "st_tri", "st_sph", "st_ell", "pp_closest", "pp_shadow", "q_closest", "q_shadow", "xf_closest", "xf_shadow", "closest_ms", "shadow_ms", "device_ms",
                              "closest_launches", "shadow_launches"], acc.tolist()))
-    rank_max = dict(zip(["closest_ms", "shadow_ms", "device_ms"], mx.tolist()[17:20]))
+    rank_max = dict(zip(["closest_ms", "shadow_ms", "device_ms"], mx.tolist()[19:22]))
 
     if rank == 0:
         rays = tot["closest_rays"] + tot["shadow_rays"]
@@ -185,6 +186,10 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": closest_tflops / PEAK_FP32_TFLOPS,
                 "traffic": measured_traffic(label, args.brute_force),
+                "executed": None if args.brute_force else {
+                    "tflops": tot["xf_closest"] / (tot["closest_ms"] * 1e-3) / 1e12 if tot["closest_ms"] > 0 else 0.0,
+                    "frac": (tot["xf_closest"] / (tot["closest_ms"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS) if tot["closest_ms"] > 0 else 0.0,
+                    "what": "FLOP of the per-ray tests the hierarchy scans executed (child records, two-stage pre-test, full test) / the same kernel time"},
                 "mode": "brute force (literal full test on every pair)" if args.brute_force else "bounding hierarchy + conservative pre-tests, full test on the survivors",
                 "note": ROOFLINE_NOTE,
                 "flop_per_launch": closest_flop / max(tot["closest_launches"], 1.0),

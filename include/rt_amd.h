@@ -124,6 +124,7 @@ typedef struct rt_stats {
     uint64_t full_tests;          /* ray-triangle tests that went through the full test after the pre-test (0 with RT_FLAG_NO_FILTER) */
     uint64_t pair_pretests[2];    /* ray-triangle pairs the per-wave (packet) pre-test left to the per-ray pre-test: closest-hit scans, shadow scans (0 with RT_FLAG_NO_FILTER) */
     uint64_t queued_pairs[2];     /* of which the per-ray pre-test kept (queued for the two-stage pre-test and the full test): closest-hit scans, shadow scans */
+    uint64_t executed_flop[2];    /* FLOP the hierarchy scans executed in per-ray tests (child records 6 cone / 18 sphere, two-stage pre-test 40, full test 54 triangle / 95 or 71 ellipsoid): closest-hit scans, shadow scans; per-wave packet tests and top-level tests not counted */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;          /* opaque: device-resident scene */

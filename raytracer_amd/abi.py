@@ -77,6 +77,7 @@ class Stats(C.Structure):
         ("full_tests", C.c_uint64),
         ("pair_pretests", C.c_uint64 * 2),
         ("queued_pairs", C.c_uint64 * 2),
+        ("executed_flop", C.c_uint64 * 2),
     ]
 
     def as_dict(self):

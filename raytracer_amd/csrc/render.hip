@@ -150,7 +150,7 @@ struct State {
 // one hot address per counter serialises the atomics of a whole launch (10 ns each).
 constexpr int STAT_COPIES = 64;
 enum { ST_SAMPLES, ST_CULLED, ST_CLOSEST_RAYS, ST_HITS, ST_SHADOW_RAYS, ST_SHADOW_BLOCKED,
-       ST_SHADOW_TESTS_TRI, ST_SHADOW_TESTS_SPH, ST_SHADOW_TESTS_ELL, ST_FULL_TESTS, ST_PAIR_PRETESTS, ST_PAIR_PRETESTS_SHADOW, ST_LIVE, ST_QUEUED, ST_QUEUED_SHADOW, ST_COUNT };
+       ST_SHADOW_TESTS_TRI, ST_SHADOW_TESTS_SPH, ST_SHADOW_TESTS_ELL, ST_FULL_TESTS, ST_PAIR_PRETESTS, ST_PAIR_PRETESTS_SHADOW, ST_LIVE, ST_QUEUED, ST_QUEUED_SHADOW, ST_FLOP, ST_FLOP_SHADOW, ST_COUNT };
 
 struct V3 { float x, y, z; };
 
@@ -1323,6 +1323,10 @@ __global__ void __launch_bounds__(BLOCK) k_closest_scan(DevScene sc, State st, u
     if (PRIM == 0) block_add_stat(stat_slot(st, ST_FULL_TESTS), n_full);
     if (lane == 0 && n_pairs) atomicAdd(stat_slot(st, ST_PAIR_PRETESTS), n_pairs);
     if (lane == 0 && n_queued) atomicAdd(stat_slot(st, ST_QUEUED), static_cast<unsigned long long>(n_queued));
+    {   // FLOP executed in per-ray tests (n_full is per lane; the others are wave totals)
+        constexpr unsigned long long CHILD = MODE == 2 ? 6 : 18, LEAF = PRIM == 0 ? 40 : 95, FULL = PRIM == 0 ? 54 : 0;
+        block_add_stat(stat_slot(st, ST_FLOP), FULL * n_full + (lane == 0 ? CHILD * n_pairs + LEAF * n_queued : 0ull));
+    }
 }
 
 template <int R>
@@ -1778,6 +1782,10 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_scan(DevScene sc, State st, ui
     if (MODE != 0 && PRIM == 0) block_add_stat(stat_slot(st, ST_FULL_TESTS), n_full);
     if ((threadIdx.x & 63u) == 0 && n_pairs) atomicAdd(stat_slot(st, ST_PAIR_PRETESTS_SHADOW), n_pairs);
     if ((threadIdx.x & 63u) == 0 && n_queued) atomicAdd(stat_slot(st, ST_QUEUED_SHADOW), static_cast<unsigned long long>(n_queued));
+    if (MODE != 0) {   // FLOP executed in per-ray tests (n_full is per lane; the others are wave totals)
+        constexpr unsigned long long CHILD = MODE == 2 ? 6 : 18, LEAF = PRIM == 0 ? 40 : 71, FULL = PRIM == 0 ? 54 : 0;
+        block_add_stat(stat_slot(st, ST_FLOP_SHADOW), FULL * n_full + ((threadIdx.x & 63u) == 0 ? CHILD * n_pairs + LEAF * n_queued : 0ull));
+    }
 }
 
 template <int R>
@@ -2287,6 +2295,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         stats->shadow_tests[0] = h[ST_SHADOW_TESTS_TRI]; stats->shadow_tests[1] = h[ST_SHADOW_TESTS_SPH]; stats->shadow_tests[2] = h[ST_SHADOW_TESTS_ELL];
         stats->full_tests = h[ST_FULL_TESTS]; stats->pair_pretests[0] = h[ST_PAIR_PRETESTS]; stats->pair_pretests[1] = h[ST_PAIR_PRETESTS_SHADOW];
         stats->queued_pairs[0] = h[ST_QUEUED]; stats->queued_pairs[1] = h[ST_QUEUED_SHADOW];
+        stats->executed_flop[0] = h[ST_FLOP]; stats->executed_flop[1] = h[ST_FLOP_SHADOW];
         float ms = 0.0f;
         if (ev_begin && ev_end && hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) stats->device_ms = ms;
         double family_ms[2] = {0.0, 0.0};

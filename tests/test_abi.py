@@ -31,12 +31,12 @@ def test_struct_sizes_match_the_header(tmp_path):
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "rt_amd.h"\n'
         'int main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(rt_scene_desc), sizeof(rt_camera_desc), sizeof(rt_render_params),'
-        ' sizeof(rt_stats), offsetof(rt_stats, queued_pairs)); return 0; }\n')
+        ' sizeof(rt_stats), offsetof(rt_stats, executed_flop)); return 0; }\n')
     exe = tmp_path / "sizes"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     sizes = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert sizes == [C.sizeof(abi.SceneDesc), C.sizeof(abi.CameraDesc), C.sizeof(abi.RenderParams), C.sizeof(abi.Stats),
-                     abi.Stats.queued_pairs.offset]
+                     abi.Stats.executed_flop.offset]
 
 
 def test_tile_partition_is_a_partition():
