@@ -2228,7 +2228,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                                static_cast<int>(ST_CLOSEST_RAYS), static_cast<int>(ST_HITS));
             hipLaunchKernelGGL(k_fill_list, dim3(ray_blocks), dim3(BLOCK), 0, stream, sb, static_cast<const uint32_t*>(sb.counts + b), 0u,
                                static_cast<const uint32_t*>(sb.list[b & 1u]), sb.list[(b + 1) & 1u]);
-            const bool overlap = b + 1 < depth;
+            const bool overlap = filter && b + 1 < depth;   // brute force is timed launch by launch: no overlap there
             hipEvent_t forked = overlap ? sync_event(2 * b) : nullptr, joined = overlap ? sync_event(2 * b + 1) : nullptr;
             if (overlap && forked && joined) {
                 HIP_TRY(hipEventRecord(forked, stream));
@@ -2265,7 +2265,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                 }
             }
             if (overlap && forked && joined) HIP_TRY(hipStreamWaitEvent(stream, joined, 0));
-            else if (overlap) closest_scans(b + 1, stream);
+            else if (b + 1 < depth) closest_scans(b + 1, stream);
         }
         hipLaunchKernelGGL(k_resolve, dim3(n_tiles), dim3(BLOCK), 0, stream, st, first, tiles_dev);
         if (ids_dev) hipLaunchKernelGGL(k_scatter_ids, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, st.primary_id, first, n_samples, f, ids_dev);
