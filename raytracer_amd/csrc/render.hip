@@ -1057,7 +1057,7 @@ DEV void load_rays(const State& st, const uint32_t* __restrict__ list_in, uint32
 constexpr uint32_t SEG_TARGET = 4096;   // workgroups a small launch is spread over
 struct ScanSplit { uint32_t ray_base, first_prim, end_prim; bool active; };
 DEV ScanSplit scan_split(uint32_t n_rays, uint32_t rays_per_block, uint32_t n_prims) {
-    constexpr uint32_t STEP = 64;   // the list is the cluster list, walked 64 records (one per lane) at a time
+    constexpr uint32_t STEP = 16;   // granule of a segment, in top nodes (the scan walks 64 at a time, one per lane; a short segment leaves lanes idle there, which is cheap)
     ScanSplit sp{0, 0, 0, false};
     const uint32_t n_blocks = (n_rays + rays_per_block - 1) / rays_per_block;
     if (n_blocks == 0) return sp;
