@@ -1049,10 +1049,10 @@ DEV void load_rays(const State& st, const uint32_t* __restrict__ list_in, uint32
     }
 }
 
-// Work split of a pre-test scan launch.  A workgroup owns BLOCK*R rays and normally walks the
-// whole triangle list.  When a launch has few rays (deep bounces) that would leave most of the
-// chip idle for the time one wave needs to walk the list, so the list is cut into S segments of
-// whole tiles and (ray block, segment) pairs are spread over the grid; results combine through
+// Work split of a hierarchy scan launch.  A workgroup owns BLOCK*R rays and normally walks the
+// whole list of top nodes.  When a launch has few rays (deep bounces, one rank's share of a frame)
+// the time of the launch is the time of its busiest wave, so the top-node list is cut into S
+// segments and (ray block, segment) pairs are spread over the grid; results combine through
 // atomicMin / atomicOr.  S is derived from the ray count alone, so every workgroup agrees on it.
 constexpr uint32_t SEG_TARGET = 4096;   // workgroups a small launch is spread over
 struct ScanSplit { uint32_t ray_base, first_prim, end_prim; bool active; };
@@ -1074,11 +1074,7 @@ DEV ScanSplit scan_split(uint32_t n_rays, uint32_t rays_per_block, uint32_t n_pr
     return sp;
 }
 
-
-// Candidate (ray, triangle) pairs a wave's first pre-test kept, queued in LDS and worked off one
-// pair per lane (drain).  This keeps the scan loop free of the registers the full test needs and
-// gives the rare full tests full lanes.
-// The pre-test scans read the 16-byte cluster records straight from memory, one record per lane
+// The hierarchy scans read the 16-byte top-node records straight from memory, one record per lane
 // (coalesced; the record arrays stay in L2).  A record the packet pre-test keeps is broadcast from
 // the lane that holds it with v_readlane.  Waves are independent: no LDS staging, no barriers.
 constexpr uint32_t SHADOW_CHECK_STEPS = 1;          // shadow scans drain and re-check "all blocked" every so many steps of 64 top nodes
