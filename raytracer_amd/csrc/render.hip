@@ -1094,6 +1094,13 @@ DEV void wave_sync() {
 // the node is a top node, a cluster or a triangle position (hence at most 2^24 triangles).
 // A push adds up to 4 entries per lane.
 constexpr uint32_t QCAP = 384, PUSH_MAX = 256;
+#ifndef RT_WALK_BATCH
+#define RT_WALK_BATCH 4
+#endif
+#ifndef RT_SCAN_ATTR
+#define RT_SCAN_ATTR
+#endif
+constexpr int WALK_BATCH = RT_WALK_BATCH;   // child records a lane has in flight while it walks a node
 constexpr uint32_t NODE_MASK = 0xFFFFFFu;
 // For every set bit b < n_bits of a lane's `bits`, append base + b*step.  Entries of one bit are contiguous, in lane order.
 DEV void push_bits(uint32_t* q, uint32_t& count, uint32_t bits, uint32_t n_bits, uint32_t base, uint32_t step) {
@@ -1134,7 +1141,7 @@ DEV float pretests_then_full(const DevScene& sc, const TriPair& f, V3 o, V3 d, u
 // (ray, leaf) pairs that remain through the full test of the kind (for triangles after the
 // two-stage pre-test).  Result: st.key[slot] / st.key_ell[slot], by atomicMin.
 template <int R, int MODE, int PRIM>
-__global__ void __launch_bounds__(BLOCK) k_closest_scan(DevScene sc, State st, uint32_t bounce) {
+__global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc, State st, uint32_t bounce) {
     static_assert(MODE != 0 || PRIM == 0, "the full-test mode of this kernel is for triangles");
     static_assert(64 * R <= PUSH_MAX && 64 * R <= 256, "a queue entry has 8 bits for the ray, a push adds at most PUSH_MAX entries");
     const Hierarchy& h = PRIM == 0 ? sc.th : sc.eh;
@@ -1266,20 +1273,20 @@ __global__ void __launch_bounds__(BLOCK) k_closest_scan(DevScene sc, State st, u
             if (MODE == 3) dd = normalise(dd);
             const V3 mm = scross(o, dd);
             const uint32_t last = n_child - 1u;
-            static_assert(CLUSTER % 8 == 0, "the walk takes 8 children at a time");
+            static_assert(CLUSTER % WALK_BATCH == 0 && WALK_BATCH % 4 == 0, "the walk takes WALK_BATCH children at a time, pushed four by four");
 #pragma nounroll
-            for (uint32_t t0 = 0; t0 < CLUSTER; t0 += 8) {     // 8 records in flight per lane
-                float4 rec[8];
+            for (uint32_t t0 = 0; t0 < CLUSTER; t0 += WALK_BATCH) {     // WALK_BATCH records in flight per lane
+                float4 rec[WALK_BATCH];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) rec[u] = child[min(first + t0 + u, last)];
+                for (int u = 0; u < WALK_BATCH; ++u) rec[u] = child[min(first + t0 + u, last)];
                 uint32_t keep_bits = 0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < WALK_BATCH; ++u) {
                     const bool keep = active && first + t0 + u <= last && ((MODE == 2 ? cone_keeps(dd, rec[u]) : sphere_keeps(dd, mm, rec[u])) || keep_all);
                     keep_bits |= keep ? 1u << u : 0u;
                 }
 #pragma nounroll
-                for (uint32_t half = 0; half < 2; ++half) {     // not unrolled: one copy of the code behind drain_out
+                for (uint32_t half = 0; half < WALK_BATCH / 4; ++half) {     // not unrolled: one copy of the code behind drain_out
                     const uint32_t bits = (keep_bits >> (4u * half)) & 15u;
                     if (__any(bits != 0u)) {
                         if (out_count + PUSH_MAX > QCAP) drain_out();
@@ -1569,7 +1576,7 @@ DEV ShadowRay make_shadow_ray(const State& st, uint32_t slot, bool point, V3 lv)
 // which the lane that holds the ray picks up after the drain; the wave stops when all its rays
 // are blocked.
 template <int R, int MODE, int PRIM>
-__global__ void __launch_bounds__(BLOCK) k_shadow_scan(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
+__global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
     static_assert(MODE != 0 || PRIM == 0, "the full-test mode of this kernel is for triangles");
     static_assert(64 * R <= PUSH_MAX && 64 * R <= 256, "a queue entry has 8 bits for the ray, a push adds at most PUSH_MAX entries");
     const Hierarchy& h = PRIM == 0 ? sc.th : sc.eh;
@@ -1685,20 +1692,20 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_scan(DevScene sc, State st, ui
             const ShadowRay s = make_shadow_ray(st, wave_slots[e >> 24], point, lv);
             const V3 mm = scross(s.o, s.d);
             const uint32_t last = n_child - 1u;
-            static_assert(CLUSTER % 8 == 0, "the walk takes 8 children at a time");
+            static_assert(CLUSTER % WALK_BATCH == 0 && WALK_BATCH % 4 == 0, "the walk takes WALK_BATCH children at a time, pushed four by four");
 #pragma nounroll
-            for (uint32_t t0 = 0; t0 < CLUSTER; t0 += 8) {     // 8 records in flight per lane
-                float4 rec[8];
+            for (uint32_t t0 = 0; t0 < CLUSTER; t0 += WALK_BATCH) {     // WALK_BATCH records in flight per lane
+                float4 rec[WALK_BATCH];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) rec[u] = child[min(first + t0 + u, last)];
+                for (int u = 0; u < WALK_BATCH; ++u) rec[u] = child[min(first + t0 + u, last)];
                 uint32_t keep_bits = 0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < WALK_BATCH; ++u) {
                     const bool keep = active && first + t0 + u <= last && ((MODE == 2 ? cone_keeps(s.d, rec[u]) : sphere_keeps(s.d, mm, rec[u])) || keep_all);
                     keep_bits |= keep ? 1u << u : 0u;
                 }
 #pragma nounroll
-                for (uint32_t half = 0; half < 2; ++half) {     // not unrolled: one copy of the code behind drain_out
+                for (uint32_t half = 0; half < WALK_BATCH / 4; ++half) {     // not unrolled: one copy of the code behind drain_out
                     const uint32_t bits = (keep_bits >> (4u * half)) & 15u;
                     if (__any(bits != 0u)) {
                         if (out_count + PUSH_MAX > QCAP) drain_out();
