@@ -312,18 +312,25 @@ DEV bool cone_keeps(V3 d, float4 c) { return !(vdot(d, xyz(c)) < c.w); }
 
 // Sphere pre-test for a ray with its own origin o, in its Pluecker coordinates (d, m = o x d)
 // with d of unit length: the distance of a point c from the ray's line is |c x d - m|.  If that
-// exceeds the radius of a sphere around c that contains the triangle (inflated by the margin m of
-// the two-stage pre-test) the ray cannot hit.  Six multiply-adds for c x d - m, three for the
-// squared length, one compare; the record (k_prep_sphere, in double) is (c, r^2) with r enlarged
-// by the rounding of m, of this expression and of the normalised direction.  r^2 = inf keeps every
-// ray; NaN keeps the ray.
-DEV bool sphere_keeps(V3 d, V3 m, float4 c) {
+// exceeds the radius of a sphere around c that contains every hit point the full test can accept
+// on the primitive, the ray cannot hit.  Six multiply-adds for c x d - m, three for the squared
+// length, one compare; the record (k_prep_sphere, in double) is (c, r^2) with r enlarged by the
+// rounding of m, of this expression and of the normalised direction.
+// Hits lie ahead of the origin, so the sphere must not lie wholly behind it either:
+// (c - o).d >= -r.  `along` is o.d lowered by SPHERE_BEHIND_SLACK * origin bound, which is more
+// than twice the rounding of u = c.d - along (both dot products, |c|_inf and |o|_inf within the
+// origin bound, d off unit length by 2^-23); the sphere is behind when u < 0 and u^2 > r^2.
+// r^2 = inf keeps every ray; NaN keeps the ray.
+constexpr float SPHERE_BEHIND_SLACK = 64.0f * 5.9604644775390625e-8f;
+DEV bool sphere_keeps(V3 d, V3 m, float along, float4 c) {
     const float vx = fma_(c.y, d.z, fma_(-c.z, d.y, -m.x));
     const float vy = fma_(c.z, d.x, fma_(-c.x, d.z, -m.y));
     const float vz = fma_(c.x, d.y, fma_(-c.y, d.x, -m.z));
     const float q = fma_(vz, vz, fma_(vy, vy, vx * vx));
-    return !(q > c.w);
+    const float u = vdot(xyz(c), d) - along;
+    return !(q > c.w) && !(u < 0.0f && u * u > c.w);
 }
+DEV float sphere_along(V3 o, V3 d, float origin_bound) { return vdot(o, d) - SPHERE_BEHIND_SLACK * origin_bound; }
 
 // Per-wave ("packet") pre-test, ahead of cone_keeps / sphere_keeps.  A wave's rays are neighbours
 // in the image, so they fit in a narrow bound: a cone of directions (unit axis A, cosine cw of the
@@ -664,7 +671,7 @@ __global__ void __launch_bounds__(BLOCK) k_prep_sphere(const float4* __restrict_
         const double r_tot = (r + 2.0 * (13.0 * eps * T + 3.0 * eps * T + 2.0 * eps * max3(c))) * (1.0 + 6.0 * eps)
                              + 2.0 * 13.0 * eps * (max3(c) + B);
         const double r2 = r_tot * r_tot * (1.0 + 1.0e-6);
-        if (r2 < 1.0e30 && m < 1.0e6)
+        if (r2 < 1.0e30 && m < 1.0e6 && max3(c) <= B)   // sphere_keeps relies on |c|_inf <= origin bound
             rec = make_float4(static_cast<float>(c[0]), static_cast<float>(c[1]), static_cast<float>(c[2]), nextafterf(static_cast<float>(r2), __builtin_inff()));
     }
     out[pos] = rec;
@@ -737,7 +744,7 @@ __global__ void __launch_bounds__(BLOCK) k_prep_cluster_sphere(const float4* __r
         const double c_max = fmax(fabs(centre[0]), fmax(fabs(centre[1]), fabs(centre[2])));
         const double r_tot = r * (1.0 + 1.0e-6) * (1.0 + 6.0 * eps) + 2.0 * 13.0 * eps * (c_max + origin_bound);
         const double r2 = r_tot * r_tot * (1.0 + 1.0e-6);
-        if (r2 < 1.0e30) rec = make_float4(cf[0], cf[1], cf[2], nextafterf(static_cast<float>(r2), __builtin_inff()));
+        if (r2 < 1.0e30 && c_max <= origin_bound) rec = make_float4(cf[0], cf[1], cf[2], nextafterf(static_cast<float>(r2), __builtin_inff()));
     }
     out[c] = rec;
 }
@@ -838,7 +845,7 @@ __global__ void __launch_bounds__(BLOCK) k_prep_ell_sphere(const float4* __restr
         const double T = 2.0 * (D + r);
         const double r_tot = (r + 2.0 * (3.0 * eps * T + 2.0 * eps * c_max)) * (1.0 + 6.0 * eps) + 2.0 * 13.0 * eps * (c_max + B);
         const double r2 = r_tot * r_tot * (1.0 + 1.0e-6);
-        if (r2 < 1.0e30) rec = make_float4(static_cast<float>(b.c[0]), static_cast<float>(b.c[1]), static_cast<float>(b.c[2]), nextafterf(static_cast<float>(r2), __builtin_inff()));
+        if (r2 < 1.0e30 && c_max <= B) rec = make_float4(static_cast<float>(b.c[0]), static_cast<float>(b.c[1]), static_cast<float>(b.c[2]), nextafterf(static_cast<float>(r2), __builtin_inff()));
     }
     out[pos] = rec;
 }
@@ -1206,6 +1213,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     uint32_t slot[R];
     bool valid[R];
     V3 d[R], moment[R];
+    float along[R];
     Packet packet;
     bool unsafe = false;    // an origin outside the bound the sphere records were built for: keep everything
     {
@@ -1219,6 +1227,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             d[r] = {st.dx[slot[r]], st.dy[slot[r]], st.dz[slot[r]]};
             if (MODE == 3) d[r] = normalise(d[r]);   // pre-test copy only: reflected directions drift off unit length
             moment[r] = scross(o[r], d[r]);
+            along[r] = sphere_along(o[r], d[r], sc.origin_bound);
             unsafe |= !(fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z))) <= sc.origin_bound);
             wave_slots[r * 64 + lane] = slot[r];
         }
@@ -1272,6 +1281,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             V3 dd{st.dx[s], st.dy[s], st.dz[s]};
             if (MODE == 3) dd = normalise(dd);
             const V3 mm = scross(o, dd);
+            const float al = sphere_along(o, dd, sc.origin_bound);
             const uint32_t last = n_child - 1u;
             static_assert(CLUSTER % WALK_BATCH == 0 && WALK_BATCH % 4 == 0, "the walk takes WALK_BATCH children at a time, pushed four by four");
 #pragma nounroll
@@ -1282,7 +1292,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
                 uint32_t keep_bits = 0;
 #pragma unroll
                 for (int u = 0; u < WALK_BATCH; ++u) {
-                    const bool keep = active && first + t0 + u <= last && ((MODE == 2 ? cone_keeps(dd, rec[u]) : sphere_keeps(dd, mm, rec[u])) || keep_all);
+                    const bool keep = active && first + t0 + u <= last && ((MODE == 2 ? cone_keeps(dd, rec[u]) : sphere_keeps(dd, mm, al, rec[u])) || keep_all);
                     keep_bits |= keep ? 1u << u : 0u;
                 }
 #pragma nounroll
@@ -1313,7 +1323,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             const float4 c = readlane4(mine, bit);
             uint32_t keep_bits = 0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) keep_bits |= ((MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], c)) || keep_all) && valid[r] ? 1u << r : 0u;
+            for (int r = 0; r < R; ++r) keep_bits |= ((MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], along[r], c)) || keep_all) && valid[r] ? 1u << r : 0u;
             if (__any(keep_bits != 0u)) {
                 if (q0_count + PUSH_MAX > QCAP) drain0();
                 push_bits(q0, q0_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
@@ -1605,6 +1615,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     uint32_t slot[R];
     bool valid[R], blocked[R];
     V3 d[R], moment[R];
+    float along[R];
     Packet packet;
     bool unsafe = false;
     {
@@ -1618,6 +1629,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             o[r] = s.o;
             d[r] = s.d;
             moment[r] = scross(s.o, s.d);
+            along[r] = sphere_along(s.o, s.d, sc.origin_bound);
             unsafe |= !(fmaxf(fabsf(s.o.x), fmaxf(fabsf(s.o.y), fabsf(s.o.z))) <= sc.origin_bound);
             blocked[r] = (st.blocked[slot[r]] & light_bit) != 0u;
             if (MODE != 0) lds_queue[(threadIdx.x >> 6) * WAVE_LDS + 3 * QCAP + r * 64 + (threadIdx.x & 63u)] = slot[r];
@@ -1691,6 +1703,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             active = active && !ray_blocked(e >> 24);
             const ShadowRay s = make_shadow_ray(st, wave_slots[e >> 24], point, lv);
             const V3 mm = scross(s.o, s.d);
+            const float al = sphere_along(s.o, s.d, sc.origin_bound);
             const uint32_t last = n_child - 1u;
             static_assert(CLUSTER % WALK_BATCH == 0 && WALK_BATCH % 4 == 0, "the walk takes WALK_BATCH children at a time, pushed four by four");
 #pragma nounroll
@@ -1701,7 +1714,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
                 uint32_t keep_bits = 0;
 #pragma unroll
                 for (int u = 0; u < WALK_BATCH; ++u) {
-                    const bool keep = active && first + t0 + u <= last && ((MODE == 2 ? cone_keeps(s.d, rec[u]) : sphere_keeps(s.d, mm, rec[u])) || keep_all);
+                    const bool keep = active && first + t0 + u <= last && ((MODE == 2 ? cone_keeps(s.d, rec[u]) : sphere_keeps(s.d, mm, al, rec[u])) || keep_all);
                     keep_bits |= keep ? 1u << u : 0u;
                 }
 #pragma nounroll
@@ -1768,7 +1781,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
                 const float4 c = readlane4(mine, bit);
                 uint32_t keep_bits = 0;
 #pragma unroll
-                for (int r = 0; r < R; ++r) keep_bits |= ((MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], c)) || keep_all) && valid[r] && !blocked[r] ? 1u << r : 0u;
+                for (int r = 0; r < R; ++r) keep_bits |= ((MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], along[r], c)) || keep_all) && valid[r] && !blocked[r] ? 1u << r : 0u;
                 if (__any(keep_bits != 0u)) {
                     if (q0_count + PUSH_MAX > QCAP) drain0();
                     push_bits(q0, q0_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
