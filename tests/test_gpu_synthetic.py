@@ -22,10 +22,11 @@ CASES = [
     dict(n_triangles=64, n_ellipsoids=3000, width=256, height=144, maxdepth=3, seed=7),                                   # ellipsoid bounds, closest and shadow
     dict(n_triangles=64, n_ellipsoids=2000, width=192, height=108, maxdepth=2, seed=8, ell_scale=(0.01, 0.05)),          # small far ellipsoids: the noise term of their bounds matters
     dict(n_triangles=64, n_ellipsoids=1000, width=192, height=108, maxdepth=2, seed=9, ell_scale=(0.002, 0.02)),         # so small that the bounds give up (keep-all records)
+    dict(n_triangles=0, n_ellipsoids=700, width=160, height=96, maxdepth=3, seed=10, ell_scale=(0.3, 1.2)),              # no triangles at all; big overlapping ellipsoids
 ]
 
 
-@pytest.mark.parametrize("kw", CASES, ids=["soup20k", "bigtris", "tinytris", "ellipsoids", "small_ellipsoids", "tiny_ellipsoids"])
+@pytest.mark.parametrize("kw", CASES, ids=["soup20k", "bigtris", "tinytris", "ellipsoids", "small_ellipsoids", "tiny_ellipsoids", "only_ellipsoids"])
 def test_pretests_are_invisible_and_match_oracle(gpu, oracle, tmp_path, kw):
     fi = gpu.FileInfo(synth.ensure_scene_file(directory=str(tmp_path), **kw))
     cam = fi.camera()
