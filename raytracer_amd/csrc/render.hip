@@ -1980,16 +1980,27 @@ __global__ void __launch_bounds__(BLOCK) k_scatter_ids(const uint32_t* __restric
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-struct Library {
-    bool ready = false;
-    int device = -1;
+// Chunks of a frame are traced on MAX_LANES "lanes" side by side: each has its own pair of streams and its
+// own ray-state arena, so the thinly filled launches of one chunk's late bounces share the chip with
+// the other chunk's early ones.
+#ifndef RT_LANES
+#define RT_LANES 2
+#endif
+constexpr uint32_t MAX_LANES = RT_LANES;
+struct Lane {
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;      // the next bounce's closest-hit scans run here, beside the shadow scans
     std::vector<hipEvent_t> sync_events;    // fork / join between the two streams (no timing)
-    // per-chunk sample state, grown on demand
-    void* state_mem = nullptr;
+    void* state_mem = nullptr;              // per-chunk sample state, grown on demand
     size_t state_samples = 0;
     uint32_t* counts = nullptr;             // 64 words
+};
+struct Library {
+    bool ready = false;
+    int device = -1;
+    Lane lanes[MAX_LANES];
+    hipStream_t stream = nullptr;           // = lanes[0].stream: uploads, scene preparation, assembly
+    hipEvent_t lanes_fork = nullptr, lanes_join[MAX_LANES] = {};
     unsigned long long* stats = nullptr;    // STAT_COPIES x ST_COUNT words
     std::vector<hipEvent_t> events;
 };
@@ -2006,6 +2017,7 @@ constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;   // brute-force scans
 constexpr uint32_t TOPS_FOR_TWO_RAYS = 1024;
 constexpr uint32_t DEFAULT_CHUNK_TILES = 32768;   // 134 M samples, 18.8 GB of ray state: a 3840x2160 frame in one chunk (long launches hide the tail of the slowest waves)
 constexpr uint32_t MAX_BOUNCES = 62;
+constexpr uint32_t MIN_LANE_TILES = 256;   // a frame is cut into chunks of at least this many tiles, one per lane
 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
@@ -2040,19 +2052,19 @@ struct rt_scene {
 
 namespace {
 
-int ensure_state(size_t samples) {
-    if (g_lib.state_samples >= samples) return 0;
-    if (g_lib.state_mem) { HIP_TRY(hipFree(g_lib.state_mem)); g_lib.state_mem = nullptr; g_lib.state_samples = 0; }
+int ensure_state(Lane& lane, size_t samples) {
+    if (lane.state_samples >= samples) return 0;
+    if (lane.state_mem) { HIP_TRY(hipFree(lane.state_mem)); lane.state_mem = nullptr; lane.state_samples = 0; }
     // 24 float arrays + hit_id + blocked + 2 lists + primary ids + three 64-bit keys = 35 words per sample
     // + per 256 samples: 4 wave ballots and one offset (ordered compaction)
-    HIP_TRY(hipMalloc(&g_lib.state_mem, samples * 35 * sizeof(float) + samples / BLOCK * 40 + SCAN_THREADS * sizeof(uint32_t)));
-    g_lib.state_samples = samples;
+    HIP_TRY(hipMalloc(&lane.state_mem, samples * 35 * sizeof(float) + samples / BLOCK * 40 + SCAN_THREADS * sizeof(uint32_t)));
+    lane.state_samples = samples;
     return 0;
 }
 
-State make_state(size_t samples, bool want_ids) {
+State make_state(const Lane& lane, size_t samples, bool want_ids) {
     State st;
-    float* f = static_cast<float*>(g_lib.state_mem);
+    float* f = static_cast<float*>(lane.state_mem);
     float** fields[] = {&st.ox, &st.oy, &st.oz, &st.dx, &st.dy, &st.dz, &st.wr, &st.wg, &st.wb, &st.cr, &st.cg, &st.cb,
                         &st.px, &st.py, &st.pz, &st.nx, &st.ny, &st.nz, &st.nox, &st.noy, &st.noz, &st.ndx, &st.ndy, &st.ndz};
     size_t k = 0;
@@ -2066,7 +2078,7 @@ State make_state(size_t samples, bool want_ids) {
     st.flag_bits = st.key_sph + samples;                               // 16-byte aligned likewise
     st.wg_offset = reinterpret_cast<uint32_t*>(st.flag_bits + samples / BLOCK * 4);
     st.scan_block = st.wg_offset + samples / BLOCK + samples / BLOCK % 2;   // after the offsets (8 bytes of the 40 per workgroup are spare)
-    st.counts = g_lib.counts;
+    st.counts = lane.counts;
     st.stats = g_lib.stats;
     return st;
 }
@@ -2095,14 +2107,14 @@ void timed(Timer* timer, int family, hipStream_t stream, Launch&& launch) {
     if (a && b) timer->spans[family].push_back({a, b});
 }
 
-// event number i of the fork/join pool
-hipEvent_t sync_event(size_t i) {
-    while (g_lib.sync_events.size() <= i) {
+// event number i of a lane's fork/join pool
+hipEvent_t sync_event(Lane& lane, size_t i) {
+    while (lane.sync_events.size() <= i) {
         hipEvent_t e;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-        g_lib.sync_events.push_back(e);
+        lane.sync_events.push_back(e);
     }
-    return g_lib.sync_events[i];
+    return lane.sync_events[i];
 }
 
 int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_render_params* prm, uint8_t* tiles_dev,
@@ -2119,8 +2131,11 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     uint32_t chunk_tiles = prm->chunk_tiles ? prm->chunk_tiles : DEFAULT_CHUNK_TILES;
     if (chunk_tiles > 65536) chunk_tiles = 65536;
     if (chunk_tiles > my_tiles) chunk_tiles = my_tiles ? my_tiles : 1;
+    // unless the caller fixed the chunk size, a frame that would be one chunk is cut into one chunk per lane
+    if (prm->chunk_tiles == 0 && my_tiles <= chunk_tiles && my_tiles >= 2 * MIN_LANE_TILES) chunk_tiles = ceil_div(my_tiles, std::min(MAX_LANES, my_tiles / MIN_LANE_TILES));
     const size_t chunk_samples = static_cast<size_t>(chunk_tiles) * SAMPLES_PER_TILE;
-    if (int rc = ensure_state(chunk_samples)) return rc;
+    const uint32_t n_lanes = std::min(MAX_LANES, ceil_div(my_tiles, chunk_tiles));
+    for (uint32_t l = 0; l < n_lanes; ++l) if (int rc = ensure_state(g_lib.lanes[l], chunk_samples)) return rc;
 
     DevScene sc = scene->dev;
     hipStream_t stream = g_lib.stream;
@@ -2157,7 +2172,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     f.rect_x0 = rect.x0; f.rect_y0 = rect.y0; f.rect_w = rect.w; f.rect_h = rect.h;
     f.tiles_x = rect.tiles_x; f.tile_rank = prm->tile_rank; f.tile_world = world;
 
-    State st = make_state(chunk_samples, ids_dev != nullptr);
+    State lane_state[MAX_LANES];
+    for (uint32_t l = 0; l < n_lanes; ++l) lane_state[l] = make_state(g_lib.lanes[l], chunk_samples, ids_dev != nullptr);
     HIP_TRY(hipMemsetAsync(g_lib.stats, 0, STAT_COPIES * ST_COUNT * sizeof(unsigned long long), stream));
 
     Timer timer_storage;
@@ -2167,10 +2183,17 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
 
     const uint32_t depth = static_cast<uint32_t>(prm->max_bounce_count);
     const bool filter = (prm->flags & RT_FLAG_NO_FILTER) == 0;
-    for (uint32_t first = 0; first < my_tiles; first += chunk_tiles) {
+    if (n_lanes > 1) {   // the other lanes start when the eye records and the cleared counters are ready
+        HIP_TRY(hipEventRecord(g_lib.lanes_fork, g_lib.lanes[0].stream));
+        for (uint32_t l = 1; l < n_lanes; ++l) HIP_TRY(hipStreamWaitEvent(g_lib.lanes[l].stream, g_lib.lanes_fork, 0));
+    }
+    for (uint32_t first = 0, chunk = 0; first < my_tiles; first += chunk_tiles, ++chunk) {
+        Lane& lane = g_lib.lanes[chunk % n_lanes];
+        const hipStream_t stream = lane.stream;       // everything of this chunk goes to its lane
+        const State st = lane_state[chunk % n_lanes];
         const uint32_t n_tiles = (my_tiles - first < chunk_tiles) ? my_tiles - first : chunk_tiles;
         const uint32_t n_samples = n_tiles * SAMPLES_PER_TILE;
-        HIP_TRY(hipMemsetAsync(g_lib.counts, 0, 64 * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(lane.counts, 0, 64 * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(k_primary, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, f, sc, st, first);
         const uint32_t scan_grid = ceil_div(n_samples / BLOCK, SCAN_THREADS);
         hipLaunchKernelGGL(k_scan_flags, dim3(scan_grid), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(nullptr), n_samples);
@@ -2245,12 +2268,12 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
             hipLaunchKernelGGL(k_fill_list, dim3(ray_blocks), dim3(BLOCK), 0, stream, sb, static_cast<const uint32_t*>(sb.counts + b), 0u,
                                static_cast<const uint32_t*>(sb.list[b & 1u]), sb.list[(b + 1) & 1u]);
             const bool overlap = filter && b + 1 < depth;   // brute force is timed launch by launch: no overlap there
-            hipEvent_t forked = overlap ? sync_event(2 * b) : nullptr, joined = overlap ? sync_event(2 * b + 1) : nullptr;
+            hipEvent_t forked = overlap ? sync_event(lane, 2 * b) : nullptr, joined = overlap ? sync_event(lane, 2 * b + 1) : nullptr;
             if (overlap && forked && joined) {
                 HIP_TRY(hipEventRecord(forked, stream));
-                HIP_TRY(hipStreamWaitEvent(g_lib.side_stream, forked, 0));
-                closest_scans(b + 1, g_lib.side_stream);
-                HIP_TRY(hipEventRecord(joined, g_lib.side_stream));
+                HIP_TRY(hipStreamWaitEvent(lane.side_stream, forked, 0));
+                closest_scans(b + 1, lane.side_stream);
+                HIP_TRY(hipEventRecord(joined, lane.side_stream));
             }
             if (sc.n_lights == 0) {
                 hipLaunchKernelGGL(k_shade, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, sb, b, 0u, 0u, 1u);
@@ -2286,6 +2309,10 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         hipLaunchKernelGGL(k_resolve, dim3(n_tiles), dim3(BLOCK), 0, stream, st, first, tiles_dev);
         if (ids_dev) hipLaunchKernelGGL(k_scatter_ids, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, st.primary_id, first, n_samples, f, ids_dev);
         HIP_TRY(hipGetLastError());
+    }
+    for (uint32_t l = 1; l < n_lanes; ++l) {
+        HIP_TRY(hipEventRecord(g_lib.lanes_join[l], g_lib.lanes[l].stream));
+        HIP_TRY(hipStreamWaitEvent(stream, g_lib.lanes_join[l], 0));
     }
     if (timer && ev_end) HIP_TRY(hipEventRecord(ev_end, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -2432,9 +2459,14 @@ int rt_init(int device) {
     HIP_TRY(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return rt_fail(RT_ERR_ARGUMENT, "rt_init: no such device");
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipStreamCreateWithFlags(&g_lib.stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&g_lib.side_stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_lib.counts), 64 * sizeof(uint32_t)));
+    for (Lane& lane : g_lib.lanes) {
+        HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&lane.side_stream, hipStreamNonBlocking));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&lane.counts), 64 * sizeof(uint32_t)));
+    }
+    g_lib.stream = g_lib.lanes[0].stream;
+    HIP_TRY(hipEventCreateWithFlags(&g_lib.lanes_fork, hipEventDisableTiming));
+    for (hipEvent_t& e : g_lib.lanes_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_lib.stats), STAT_COPIES * ST_COUNT * sizeof(unsigned long long)));
     g_lib.device = device;
     g_lib.ready = true;
