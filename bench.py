@@ -4,7 +4,8 @@ over the ranks (one process per GPU), framebuffer assembled on rank 0 from an RC
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload scene7_4k|scene1|...|synthetic]
 
-Prints one JSON line on rank 0 (see README / DESIGN.md for the fields).  For N > 1 launch with
+Prints one JSON line on rank 0: metric, value, unit, n_gpus, steps, warmup, ms_per_step, ..., `roofline` (closest-hit
+scan kernels against the FP32 vector peak) and `cpu_baseline` (the CPU renderer on a crop of the same frame).  For N > 1 launch with
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse

@@ -74,9 +74,12 @@ constexpr uint32_t CLUSTER = RT_CLUSTER;          // triangles per cluster of th
 constexpr uint32_t SAMPLES_PER_TILE = RT_TILE * RT_TILE * RT_SAMPLES_PER_PIXEL;  // 4096
 
 // Primitive lists are stored in "scan order": entry k holds the primitive the reference
-// keeps in lane j = k / nb of batch i = k % nb (original index 8*i + j).  Walking k upward
-// with a strict `<` then yields the reference's winner among equal distances, which is the
-// smallest (distance, lane, batch), not the smallest index (ray_tracing.cpp:489-516).
+// keeps in lane j = k / nb of batch i = k % nb (original index 8*i + j).  The reference's winner
+// among equal distances is the smallest (distance, lane, batch), not the smallest index
+// (ray_tracing.cpp:489-516): that is the smallest (distance, k), which the brute-force scans get
+// by walking k upward with a strict `<` and the hierarchy scans by an atomicMin over
+// (distance, k) keys (pack_hit).
+
 // Bounding records of one primitive kind (triangles or ellipsoids), 1 x float4 each, for the
 // conservative pre-tests of the scans.  Three kinds of record: "eye" = cone of directions from the
 // camera eye (cone_keeps), "light" = the same from each point light, "sphere" = bounding sphere for
@@ -271,8 +274,11 @@ DEV float hit_triangle(V3 o, V3 d, float4 t0, float4 t1, float4 t2, float nn) {
 // full test's barycentrics are alpha = w1.(p - a), beta = w2.(p - a) in real arithmetic.
 // Here t1 = ((a-o).n) * rcp(d.n) (the same two dot products, bit for bit, as the full test,
 // and a reciprocal instead of a division), ap = t1*d - (a-o), alpha1 = w1.ap, beta1 = w2.ap.
-// A rounding analysis of both evaluation orders ("Pre-test margin") bounds
-// |alpha1 - alpha| and |beta1 - beta| by
+// Rounding: the full test's hit point is off by 3 eps S per component (S = |o|_inf + |t| + |a|_inf),
+// its cross, dot and division add 30 eps Q |ap|_inf + eps, propagated through w1 (|w1|_1 <= 6Q)
+// 18 eps Q S: 48 eps Q S + eps in all.  Here rcp is within 1 ulp (5 eps |t| on t1, times 6Q),
+// the stored w1 is off by 8 eps Q per component and the dot adds its own roundings: 54 + 30
+// eps Q S.  Together |alpha1 - alpha| and |beta1 - beta| are bounded by
 //     m = 132 eps Q (|o|_inf + |t| + |a|_inf) + eps,  Q = |n|_inf max(|a_to_b|_inf, |a_to_c|_inf)/nn,
 // eps = 2^-24.  With G = 2^-15 Q (about four times 132 eps Q) and H = G |a|_inf + 2^-22,
 // m <= G (|t1| + |o|_inf) + H.  Stage 1 keeps a ray when alpha1 is within [-2m, 1 + 2m], stage 2
@@ -1407,7 +1413,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest_ell(DevScene sc, State st, ui
 }
 
 // k_hit: one ray per thread.  Kind choice (ray_tracing.cpp:610-680), hit point, normal,
-// ambient + emission (:682), and the order-preserving list of rays that go on.
+// ambient + emission (:682), the reflected ray, and the flag "this ray goes on" for the list compaction.
 __global__ void __launch_bounds__(BLOCK) k_hit(DevScene sc, State st, uint32_t bounce) {
     const uint32_t n_rays = st.counts[bounce];
     const uint32_t base = blockIdx.x * BLOCK;
@@ -2350,8 +2356,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     return 0;
 }
 
-// Cluster order of the triangles: the scan indices in the leaf order of a kd tree over their
-// centroids, degenerate and non-finite triangles last.  A range of more than CLUSTER*CLUSTER
+// Cluster order of the primitives of one kind: the scan indices in the leaf order of a kd tree over
+// their centroids, degenerate and non-finite primitives last.  A range of more than CLUSTER*CLUSTER
 // triangles is split at a multiple of CLUSTER*CLUSTER near its middle along its longest axis,
 // a smaller one at a multiple of CLUSTER, so that every aligned group of CLUSTER positions is one
 // leaf (a compact patch) and every aligned group of CLUSTER clusters one subtree.
