@@ -41,23 +41,22 @@ def parse_args():
 
 
 def load_workload(api, name, width, height, maxdepth):
-    """Returns (FileInfo, label)."""
+    """Returns (FileInfo, label, seconds the parser took)."""
     scenes = os.path.join(ROOT, "tests", "golden", "scenes")
-    if name == "scene7_4k":
-        fi = api.FileInfo(os.path.join(scenes, "scene7.test"))
-        fi.set_size(width or 3840, height or 2160)
-    elif name == "synthetic":
+    if name == "synthetic":
         from raytracer_amd import synth
-        path = synth.ensure_scene_file()
-        fi = api.FileInfo(path)
-        if width and height:
-            fi.set_size(width, height)
+        path = synth.ensure_scene_file()        # generated on first use (not timed)
     else:
-        fi = api.FileInfo(os.path.join(scenes, name + ".test"))
-        if width and height:
-            fi.set_size(width, height)
+        path = os.path.join(scenes, (name.replace("_4k", "")) + ".test")
+    t0 = time.perf_counter()
+    fi = api.FileInfo(path)
+    parse_s = time.perf_counter() - t0
+    if name == "scene7_4k":
+        fi.set_size(width or 3840, height or 2160)
+    elif width and height:
+        fi.set_size(width, height)
     label = "%s@%dx%d" % (name.replace("_4k", ""), fi.width, fi.height)
-    return fi, label
+    return fi, label, parse_s
 
 
 def flops_of(stats, n_point_lights_share=1.0):
@@ -87,10 +86,12 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     api.init(local_rank)
 
-    fi, label = load_workload(api, args.workload, args.width, args.height, args.maxdepth)
+    fi, label, parse_s = load_workload(api, args.workload, args.width, args.height, args.maxdepth)
     depth = fi.max_recursion_depth if args.maxdepth < 0 else args.maxdepth
     cam = fi.camera()
-    scene = api.Scene(fi.scene_desc)
+    t_setup = time.perf_counter()
+    scene = api.Scene(fi.scene_desc)     # upload, re-packing on the GPU, bounding hierarchy (kd ordering on the host)
+    scene_create_s = time.perf_counter() - t_setup
     flags = abi.RT_FLAG_NO_FILTER if args.brute_force else 0
     prm = fi.params(max_bounce_count=depth, tile_rank=rank, tile_world=world, flags=flags, chunk_tiles=args.chunk_tiles)
     stride = distributed.stride_tiles(prm, world)      # tiles per rank in the gathered buffer
@@ -201,6 +202,7 @@ def main():
                 "whole_step_tflops": (closest_flop + shadow_flop) / elapsed / 1e12 / world,
             },
             "per_rank_max_ms": {k: v / args.steps for k, v in rank_max.items()},
+            "setup_ms": {"parse_scene_file": parse_s * 1e3, "scene_create": scene_create_s * 1e3},   # rank 0, outside the timed steps
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(api, abi, fi, cam, scene, depth, args.cpu_crop)
