@@ -70,3 +70,19 @@ def test_pretest_does_not_change_results(gpu, name):
     assert b["stats"].full_tests == 0
     if fi.scene_desc.n_triangles:
         assert 0 < a["stats"].full_tests
+
+
+@pytest.mark.parametrize("name", ["scene6", "scene7"])
+def test_chunking_does_not_change_results(gpu, name):
+    """A frame traced as many small chunks (alternating between the two lanes, arenas reused in
+    stream order, last chunk partial) equals the frame traced in the default way."""
+    fi = gpu.FileInfo(scene_path(name))
+    cam = fi.camera()
+    scene = gpu.Scene(fi.scene_desc)
+    whole = scene.render(cam, fi.params(), want_ids=True)                      # 1200 tiles: two chunks, one per lane
+    for chunk_tiles in (1200, 101, 7 if name == "scene6" else 173):
+        part = scene.render(cam, fi.params(chunk_tiles=chunk_tiles), want_ids=True)
+        assert np.array_equal(part["rgb"], whole["rgb"]) and np.array_equal(part["ids"], whole["ids"])
+        for f in ("samples", "culled", "closest_rays", "hits", "shadow_rays", "shadow_blocked"):
+            assert getattr(part["stats"], f) == getattr(whole["stats"], f), (chunk_tiles, f)
+    scene.close()
