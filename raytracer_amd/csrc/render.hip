@@ -80,7 +80,7 @@ constexpr uint32_t SAMPLES_PER_TILE = RT_TILE * RT_TILE * RT_SAMPLES_PER_PIXEL; 
 // by walking k upward with a strict `<` and the hierarchy scans by an atomicMin over
 // (distance, k) keys (pack_hit).
 
-// Bounding records of one primitive kind (triangles or ellipsoids), 1 x float4 each, for the
+// Bounding records of one primitive kind (triangles, ellipsoids or spheres), 1 x float4 each, for the
 // conservative pre-tests of the scans.  Three kinds of record: "eye" = cone of directions from the
 // camera eye (cone_keeps), "light" = the same from each point light, "sphere" = bounding sphere for
 // rays with their own origin (sphere_keeps).  Three levels: leaves (one per primitive), clusters
@@ -102,6 +102,7 @@ struct DevScene {
     const float4* trif_pos;  // the same in cluster order (th.k_of), with the scan index in the spare word [2].w
     Hierarchy th;        // bounding records of the triangles, see Hierarchy
     Hierarchy eh;        // bounding records of the ellipsoids
+    Hierarchy sh;        // bounding records of the spheres
     const float4* sph;   // (centre, radius)
     const float4* ell;   // 6 x float4: rows of the inverse transform, rows of the transform
     const float4* ell_light;  // [point light][ellipsoid]: inverse transform applied to the light position
@@ -137,7 +138,7 @@ struct State {
     float *px, *py, *pz, *nx, *ny, *nz;   // hit point and unit normal of the current bounce
     unsigned long long* key;              // closest triangle of the current bounce, see pack_hit
     unsigned long long* key_ell;          // closest ellipsoid of the current bounce, same format
-    unsigned long long* key_sph;          // closest sphere of the current bounce, same format
+    unsigned long long* key_sph;          // closest sphere of the current bounce, see pack_hit_signed
     uint32_t* hit_id;                     // RT_ID_MAKE(kind, original index) of the current bounce
     uint32_t* blocked;                    // bit l: light l of the current group is blocked
     uint32_t* list[2];                    // compacted slots of live rays, ping-pong
@@ -211,6 +212,19 @@ DEV V3 smat_transpose_dir(float4 r0, float4 r1, float4 r2, V3 v) {
 // order of the keys is the order of (distance, scan index): atomicMin keeps the reference's winner.
 DEV unsigned long long pack_hit(float t, uint32_t k) { return (static_cast<unsigned long long>(__float_as_uint(t)) << 32) | k; }
 constexpr unsigned long long NO_HIT_KEY = ~0ull;
+// The sphere test can return a distance below the tolerance, negative ones included (hit_sphere:
+// an origin inside a sphere gets the near root).  The high word is therefore the distance mapped
+// to an unsigned number of the same order (sign bit flipped for positive values, all bits for
+// negative ones).  -0 sorts before +0 here while the reference treats them as equal; two spheres
+// that return zeros of different sign for one ray are not expected to exist.
+DEV unsigned long long pack_hit_signed(float t, uint32_t k) {
+    const uint32_t b = __float_as_uint(t);
+    return (static_cast<unsigned long long>(b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u)) << 32) | k;
+}
+DEV float unpack_distance_signed(unsigned long long key) {
+    const uint32_t b = static_cast<uint32_t>(key >> 32);
+    return __uint_as_float(b ^ ((b >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
 
 // fp_pow and its helpers (maths.cpp:9-139)
 DEV int exponent_127(float x) { return static_cast<int>((__float_as_uint(x) >> 23) & 0xFFu); }
@@ -892,6 +906,80 @@ __global__ void __launch_bounds__(BLOCK) k_prep_ell_cone(const float4* __restric
     out[pos] = rec;
 }
 
+// ---- bounding records of the spheres (all in double) ----
+// hit_sphere accepts when r*r - (oc.oc - (oc.d)^2) >= 0 in binary32, oc = c - o.  With |oc| <= D the
+// roundings of oc (relative 2^-24 per component), of the two dot products, of the square and of
+// the difference move perp2 by less than 11 eps D^2, and a direction longer than 1 lowers it by
+// (|d|^2 - 1) (oc.d)^2 <= SPH_DIR_SLACK * D^2: reflected directions are not renormalised, and the
+// scans keep every sphere for a wave that holds a ray with |d|^2 beyond 1 + SPH_DIR_SLACK (as
+// evaluated: SPH_DIR_CHECK).  A line the test accepts therefore passes within
+// sqrt(r^2 + (16 eps + SPH_DIR_SLACK) D^2) of the centre.  The distance the test returns can be negative (origin
+// inside the sphere); such a sphere is neither behind the origin for sphere_keeps nor outside a
+// cone of directions through the origin, so the pre-tests need no special case for it.
+constexpr float SPH_DIR_SLACK = 32.0f * 5.9604644775390625e-8f;
+constexpr float SPH_DIR_CHECK = 1.0f + 28.0f * 5.9604644775390625e-8f;   // |d|^2 as evaluated carries up to 3 eps
+__device__ double sph_reach(double r, double D) {
+    const double eps = 5.9604644775390625e-8;   // 2^-24
+    return sqrt(r * r * (1.0 + 4.0 * eps) + (16.0 * eps + SPH_DIR_SLACK) * D * D) * (1.0 + 1.0e-6) + 4.0 * eps * D;
+}
+__device__ bool sph_usable(float4 s) { return isfinite(s.x) && isfinite(s.y) && isfinite(s.z) && isfinite(s.w); }
+// sphere records (sphere_keeps) of the spheres, in cluster order
+__global__ void __launch_bounds__(BLOCK) k_prep_sph_sphere(const float4* __restrict__ sph, const uint32_t* __restrict__ k_of, uint32_t n, float origin_bound, float4* __restrict__ out) {
+    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
+    if (pos >= n) return;
+    const float4 s = sph[k_of[pos]];
+    float4 rec = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());   // keeps every ray
+    if (sph_usable(s)) {
+        const double eps = 5.9604644775390625e-8;
+        const double B = origin_bound;
+        const double c[3] = {s.x, s.y, s.z};
+        const double c_len = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+        const double c_max = fmax(fabs(c[0]), fmax(fabs(c[1]), fabs(c[2])));
+        const double D = 1.7320508075688772 * B + c_len;
+        const double r = sph_reach(fabs(static_cast<double>(s.w)), D);
+        // as in k_prep_sphere: the pre-test's re-normalised direction, m = o x d and c x d - m
+        const double T = 2.0 * (D + r);
+        const double r_tot = (r + 2.0 * (3.0 * eps * T + 2.0 * eps * c_max)) * (1.0 + 6.0 * eps) + 2.0 * 13.0 * eps * (c_max + B);
+        const double r2 = r_tot * r_tot * (1.0 + 1.0e-6);
+        if (r2 < 1.0e30 && c_max <= B) rec = make_float4(s.x, s.y, s.z, nextafterf(static_cast<float>(r2), __builtin_inff()));
+    }
+    out[pos] = rec;
+}
+// cone records (cone_keeps) of the spheres for rays through X; `reversed` as in k_prep_ell_cone
+__global__ void __launch_bounds__(BLOCK) k_prep_sph_cone(const float4* __restrict__ sph, const uint32_t* __restrict__ k_of, uint32_t n, float x, float y, float z,
+                                                         float origin_bound, int reversed, float4* __restrict__ out) {
+    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
+    if (pos >= n) return;
+    const float4 s = sph[k_of[pos]];
+    float4 rec = make_float4(0.0f, 0.0f, 0.0f, -2.0f);   // keeps every ray
+    if (sph_usable(s)) {
+        const double eps = 5.9604644775390625e-8;
+        const double X[3] = {x, y, z};
+        const double c[3] = {s.x, s.y, s.z};
+        const double to_c[3] = {c[0] - X[0], c[1] - X[1], c[2] - X[2]};
+        const double dist = sqrt(to_c[0] * to_c[0] + to_c[1] * to_c[1] + to_c[2] * to_c[2]);
+        const double x_max = fmax(fabs(X[0]), fmax(fabs(X[1]), fabs(X[2])));
+        const double c_len = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+        const double D = reversed ? 1.7320508075688772 * origin_bound + c_len : dist;
+        const double r = sph_reach(fabs(static_cast<double>(s.w)), D);
+        // a shadow ray's direction is a rounded quotient: its line misses X by up to 8 eps of the origin's distance from X
+        const double T_x = 2.0 * (1.7320508075688772 * origin_bound + x_max * 1.7320508075688772);
+        const double delta = reversed ? 2.0 * 8.0 * eps * T_x : 0.0;
+        const double reach = r + delta;
+        if (reach < 1.0e30 && dist > 1.01 * reach + 1.0e-30) {
+            const double theta = asin(reach / dist) + 1.0e-6;
+            if (theta < 1.5) {
+                const double cos_store = cos(theta) * (1.0 - 8.0 * eps) - 16.0 * eps;
+                const double sign = reversed ? -1.0 : 1.0;
+                rec = make_float4(static_cast<float>(sign * to_c[0] / dist), static_cast<float>(sign * to_c[1] / dist), static_cast<float>(sign * to_c[2] / dist),
+                                  nextafterf(static_cast<float>(cos_store), -2.0f));
+                if (!(rec.w > -1.0f && rec.w < 1.0f)) rec = make_float4(0.0f, 0.0f, 0.0f, -2.0f);
+            }
+        }
+    }
+    out[pos] = rec;
+}
+
 // inverse transform applied to each point light's position (ray_tracing.cpp:388), once per scene
 __global__ void __launch_bounds__(BLOCK) k_prep_ellipsoid_lights(const float4* __restrict__ ell, uint32_t n_ell, const float* __restrict__ point_lights,
                                                                  uint32_t n_point, float4* __restrict__ out) {
@@ -1144,7 +1232,7 @@ DEV float pretests_then_full(const DevScene& sc, const TriPair& f, V3 o, V3 d, u
     return hit_triangle(o, d, rec[0], rec[1], rec[2], rec[3].x);
 }
 
-// Closest hit of every live ray over the primitives of kind PRIM (0 triangles, 1 ellipsoids).
+// Closest hit of every live ray over the primitives of kind PRIM (0 triangles, 1 ellipsoids, 2 spheres).
 // MODE 0: brute force, every triangle through the full test (RT_FLAG_NO_FILTER): tiles of records
 // staged in LDS, broadcast reads, per-lane running minimum.
 // MODE 2 (rays from the eye, cone records) and 3 (rays with their own origin, sphere records):
@@ -1152,12 +1240,12 @@ DEV float pretests_then_full(const DevScene& sc, const TriPair& f, V3 o, V3 d, u
 // the bound of the whole wave (packet test), then per ray; (ray, node) pairs go through three
 // per-wave queues in LDS (top node -> cluster -> leaf), each walked one pair per lane, and the
 // (ray, leaf) pairs that remain through the full test of the kind (for triangles after the
-// two-stage pre-test).  Result: st.key[slot] / st.key_ell[slot], by atomicMin.
+// two-stage pre-test).  Result: st.key[slot] / st.key_ell[slot] / st.key_sph[slot], by atomicMin.
 template <int R, int MODE, int PRIM>
 __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc, State st, uint32_t bounce) {
     static_assert(MODE != 0 || PRIM == 0, "the full-test mode of this kernel is for triangles");
     static_assert(64 * R <= PUSH_MAX && 64 * R <= 256, "a queue entry has 8 bits for the ray, a push adds at most PUSH_MAX entries");
-    const Hierarchy& h = PRIM == 0 ? sc.th : sc.eh;
+    const Hierarchy& h = PRIM == 0 ? sc.th : (PRIM == 1 ? sc.eh : sc.sh);
     constexpr int WORDS = 4;
     __shared__ float4 lds[MODE == 0 ? TILE_PRIMS * WORDS : 1];   // record tiles, full-test mode only
     constexpr uint32_t WAVE_LDS = 3 * QCAP + 64 * R;   // per wave: (ray, top node), (ray, cluster) and (ray, triangle) queues, slot table
@@ -1231,6 +1319,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             slot[r] = list_in[valid[r] ? i : base];
             o[r] = {st.ox[slot[r]], st.oy[slot[r]], st.oz[slot[r]]};
             d[r] = {st.dx[slot[r]], st.dy[slot[r]], st.dz[slot[r]]};
+            if (PRIM == 2) unsafe |= !(vdot(d[r], d[r]) <= SPH_DIR_CHECK);   // the sphere bounds allow for this much extra length only
             if (MODE == 3) d[r] = normalise(d[r]);   // pre-test copy only: reflected directions drift off unit length
             moment[r] = scross(o[r], d[r]);
             along[r] = sphere_along(o[r], d[r], sc.origin_bound);
@@ -1239,7 +1328,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
         }
         packet = uniform_packet(make_packet<R>(d, MODE == 3 ? o : nullptr, valid));
     }
-    const bool keep_all = MODE == 3 && __any(unsafe);
+    const bool keep_all = (MODE == 3 || PRIM == 2) && __any(unsafe);
     const float4* __restrict__ top_stream = MODE == 2 ? h.top_eye : h.top_sphere;
     const float4* __restrict__ cluster_stream = MODE == 2 ? h.cl_eye : h.cl_sphere;
     const float4* __restrict__ leaf_stream = MODE == 2 ? h.leaf_eye : h.leaf_sphere;
@@ -1257,7 +1346,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
                 const float t = pretests_then_full(sc, load_tri_pair(sc, e & NODE_MASK), o, dd, n_full, k);
                 if (t < FLT_MAX) atomicMin(&st.key[s], pack_hit(t, k));
             }
-        } else {
+        } else if (PRIM == 1) {
             for (uint32_t i = lane; i < q2_count; i += 64) {
                 const uint32_t e = q2[i];
                 const uint32_t s = wave_slots[e >> 24];
@@ -1268,6 +1357,17 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
                 const float t = hit_ellipsoid(o, dd, rec[0], rec[1], rec[2], rec[3], rec[4], rec[5]);
                 n_full++;
                 if (t < FLT_MAX) atomicMin(&st.key_ell[s], pack_hit(t, k));
+            }
+        } else {
+            for (uint32_t i = lane; i < q2_count; i += 64) {
+                const uint32_t e = q2[i];
+                const uint32_t s = wave_slots[e >> 24];
+                const V3 o{st.ox[s], st.oy[s], st.oz[s]};
+                const V3 dd{st.dx[s], st.dy[s], st.dz[s]};
+                const uint32_t k = h.k_of[e & NODE_MASK];
+                const float t = hit_sphere(o, dd, sc.sph[k]);
+                n_full++;
+                if (t < FLT_MAX) atomicMin(&st.key_sph[s], pack_hit_signed(t, k));
             }
         }
         wave_sync();
@@ -1343,7 +1443,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     if (lane == 0 && n_pairs) atomicAdd(stat_slot(st, ST_PAIR_PRETESTS), n_pairs);
     if (lane == 0 && n_queued) atomicAdd(stat_slot(st, ST_QUEUED), static_cast<unsigned long long>(n_queued));
     {   // FLOP executed in per-ray tests (n_full is per lane; the others are wave totals)
-        constexpr unsigned long long CHILD = MODE == 2 ? 6 : 18, LEAF = PRIM == 0 ? 40 : 95, FULL = PRIM == 0 ? 54 : 0;
+        constexpr unsigned long long CHILD = MODE == 2 ? 6 : 18, LEAF = PRIM == 0 ? 40 : (PRIM == 1 ? 95 : 19), FULL = PRIM == 0 ? 54 : 0;
         block_add_stat(stat_slot(st, ST_FLOP), FULL * n_full + (lane == 0 ? CHILD * n_pairs + LEAF * n_queued : 0ull));
     }
 }
@@ -1377,7 +1477,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest_sph(DevScene sc, State st, ui
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) if (valid[r]) st.key_sph[slot[r]] = best_k[r] == 0xFFFFFFFFu ? NO_HIT_KEY : pack_hit(best_t[r], best_k[r]);
+    for (int r = 0; r < R; ++r) if (valid[r]) st.key_sph[slot[r]] = best_k[r] == 0xFFFFFFFFu ? NO_HIT_KEY : pack_hit_signed(best_t[r], best_k[r]);
 }
 
 template <int R>
@@ -1432,7 +1532,7 @@ __global__ void __launch_bounds__(BLOCK) k_hit(DevScene sc, State st, uint32_t b
     if (sc.n_sph) {
         const unsigned long long key = st.key_sph[s];
         k_kind[1] = static_cast<uint32_t>(key & 0xFFFFFFFFull);
-        if (k_kind[1] != 0xFFFFFFFFu) t_kind[1] = __uint_as_float(static_cast<uint32_t>(key >> 32));
+        if (k_kind[1] != 0xFFFFFFFFu) t_kind[1] = unpack_distance_signed(key);
     }
     if (sc.n_ell) {
         const unsigned long long key = st.key_ell[s];
@@ -1595,7 +1695,7 @@ template <int R, int MODE, int PRIM>
 __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
     static_assert(MODE != 0 || PRIM == 0, "the full-test mode of this kernel is for triangles");
     static_assert(64 * R <= PUSH_MAX && 64 * R <= 256, "a queue entry has 8 bits for the ray, a push adds at most PUSH_MAX entries");
-    const Hierarchy& h = PRIM == 0 ? sc.th : sc.eh;
+    const Hierarchy& h = PRIM == 0 ? sc.th : (PRIM == 1 ? sc.eh : sc.sh);
     constexpr int WORDS = 4;
     __shared__ float4 lds[MODE == 0 ? TILE_PRIMS * WORDS : 1];   // record tiles, full-test mode only
     constexpr uint32_t WAVE_LDS = 3 * QCAP + 64 * R;   // per wave: (ray, top node), (ray, cluster) and (ray, triangle) queues, slot table
@@ -1637,6 +1737,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             moment[r] = scross(s.o, s.d);
             along[r] = sphere_along(s.o, s.d, sc.origin_bound);
             unsafe |= !(fmaxf(fabsf(s.o.x), fmaxf(fabsf(s.o.y), fabsf(s.o.z))) <= sc.origin_bound);
+            if (!point) unsafe |= !(vdot(s.d, s.d) <= SPH_DIR_CHECK);   // a directional light's direction is the caller's: the pre-tests need unit length
             blocked[r] = (st.blocked[slot[r]] & light_bit) != 0u;
             if (MODE != 0) lds_queue[(threadIdx.x >> 6) * WAVE_LDS + 3 * QCAP + r * 64 + (threadIdx.x & 63u)] = slot[r];
         }
@@ -1677,6 +1778,14 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
                 const ShadowRay s = make_shadow_ray(st, wave_slots[ray], point, lv);
                 uint32_t k;
                 if (pretests_then_full(sc, load_tri_pair(sc, e & NODE_MASK), s.o, s.d, n_full, k) < s.limit) atomicOr(&lds_blocked[wave * 64u + (ray & 63u)], 1u << (ray >> 6));
+            }
+        } else if (PRIM == 2) {
+            for (uint32_t i = lane; i < q2_count; i += 64) {
+                const uint32_t e = q2[i];
+                const uint32_t ray = e >> 24;
+                const ShadowRay s = make_shadow_ray(st, wave_slots[ray], point, lv);
+                n_full++;
+                if (hit_sphere(s.o, s.d, sc.sph[h.k_of[e & NODE_MASK]]) < s.limit) atomicOr(&lds_blocked[wave * 64u + (ray & 63u)], 1u << (ray >> 6));
             }
         } else {
             for (uint32_t i = lane; i < q2_count; i += 64) {
@@ -1800,12 +1909,12 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if (valid[r] && blocked[r]) atomicOr(&st.blocked[slot[r]], light_bit);
-    if ((threadIdx.x & 63u) == 0 && wave_tests) atomicAdd(stat_slot(st, PRIM == 0 ? ST_SHADOW_TESTS_TRI : ST_SHADOW_TESTS_ELL), wave_tests);
+    if ((threadIdx.x & 63u) == 0 && wave_tests) atomicAdd(stat_slot(st, PRIM == 0 ? ST_SHADOW_TESTS_TRI : (PRIM == 1 ? ST_SHADOW_TESTS_ELL : ST_SHADOW_TESTS_SPH)), wave_tests);
     if (MODE != 0 && PRIM == 0) block_add_stat(stat_slot(st, ST_FULL_TESTS), n_full);
     if ((threadIdx.x & 63u) == 0 && n_pairs) atomicAdd(stat_slot(st, ST_PAIR_PRETESTS_SHADOW), n_pairs);
     if ((threadIdx.x & 63u) == 0 && n_queued) atomicAdd(stat_slot(st, ST_QUEUED_SHADOW), static_cast<unsigned long long>(n_queued));
     if (MODE != 0) {   // FLOP executed in per-ray tests (n_full is per lane; the others are wave totals)
-        constexpr unsigned long long CHILD = MODE == 2 ? 6 : 18, LEAF = PRIM == 0 ? 40 : 71, FULL = PRIM == 0 ? 54 : 0;
+        constexpr unsigned long long CHILD = MODE == 2 ? 6 : 18, LEAF = PRIM == 0 ? 40 : (PRIM == 1 ? 71 : 19), FULL = PRIM == 0 ? 54 : 0;
         block_add_stat(stat_slot(st, ST_FLOP_SHADOW), FULL * n_full + ((threadIdx.x & 63u) == 0 ? CHILD * n_pairs + LEAF * n_queued : 0ull));
     }
 }
@@ -2051,7 +2160,7 @@ struct rt_scene {
     std::vector<void*> allocations;
     // cone records for rays from the eye, rebuilt when the eye moves (one render at a time per scene)
     struct EyeRecords { float4 *leaf = nullptr, *cl = nullptr, *top = nullptr; };
-    mutable EyeRecords eye_tri, eye_ell;
+    mutable EyeRecords eye_tri, eye_ell, eye_sph;
     mutable float eye[3] = {0, 0, 0};
     mutable bool eye_valid = false;
 };
@@ -2123,6 +2232,19 @@ hipEvent_t sync_event(Lane& lane, size_t i) {
     return lane.sync_events[i];
 }
 
+const Hierarchy& hierarchy_of(const DevScene& sc, int prim) { return prim == 0 ? sc.th : (prim == 1 ? sc.eh : sc.sh); }
+// hierarchy scans of one kind: rays per lane (1 or 2) and record kind (cone records for rays through a common point, else sphere records)
+template <int PRIM>
+void launch_closest_scan(bool two, bool eye_rays, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b) {
+    if (eye_rays) { if (two) hipLaunchKernelGGL((k_closest_scan<2, 2, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b); else hipLaunchKernelGGL((k_closest_scan<1, 2, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b); }
+    else { if (two) hipLaunchKernelGGL((k_closest_scan<2, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b); else hipLaunchKernelGGL((k_closest_scan<1, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b); }
+}
+template <int PRIM>
+void launch_shadow_scan(bool two, bool point_lights, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b, uint32_t first_light, uint32_t group_first) {
+    if (point_lights) { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 2, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 2, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first); }
+    else { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first); }
+}
+
 int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_render_params* prm, uint8_t* tiles_dev,
                 uint32_t* ids_dev /* rect-shaped, nullable */, rt_stats* stats) {
     if (!g_lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
@@ -2161,12 +2283,18 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                                cam->eye[0], cam->eye[1], cam->eye[2], sc.origin_bound, 0, scene->eye_ell.leaf);
             rebuild(sc.eh, scene->eye_ell);
         }
+        if (sc.n_sph) {
+            hipLaunchKernelGGL(k_prep_sph_cone, dim3(ceil_div(sc.n_sph, BLOCK)), dim3(BLOCK), 0, stream, sc.sph, sc.sh.k_of, sc.n_sph,
+                               cam->eye[0], cam->eye[1], cam->eye[2], sc.origin_bound, 0, scene->eye_sph.leaf);
+            rebuild(sc.sh, scene->eye_sph);
+        }
         HIP_TRY(hipGetLastError());
         std::memcpy(scene->eye, cam->eye, sizeof scene->eye);
         scene->eye_valid = true;
     }
     sc.th.leaf_eye = scene->eye_tri.leaf; sc.th.cl_eye = scene->eye_tri.cl; sc.th.top_eye = scene->eye_tri.top;
     sc.eh.leaf_eye = scene->eye_ell.leaf; sc.eh.cl_eye = scene->eye_ell.cl; sc.eh.top_eye = scene->eye_ell.top;
+    sc.sh.leaf_eye = scene->eye_sph.leaf; sc.sh.cl_eye = scene->eye_sph.cl; sc.sh.top_eye = scene->eye_sph.top;
     Frame f;
     std::memcpy(f.eye, cam->eye, sizeof f.eye);
     std::memcpy(f.bi, cam->basis_i, sizeof f.bi);
@@ -2225,23 +2353,21 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         auto closest_scans = [&](uint32_t b, hipStream_t on) {
             const State sb = state_of(b);
             auto hierarchy_scan = [&](int prim) {   // one or two rays per lane (TOPS_FOR_TWO_RAYS)
-                const bool two = (prim == 0 ? sc.th : sc.eh).n_tops > TOPS_FOR_TWO_RAYS;
+                const bool two = hierarchy_of(sc, prim).n_tops > TOPS_FOR_TWO_RAYS;
                 const dim3 grid(blocks_for(two ? 2 : 1));
-                const bool eye_rays = b == 0;
-                if (prim == 0) {
-                    if (eye_rays) { if (two) hipLaunchKernelGGL((k_closest_scan<2, 2, 0>), grid, dim3(BLOCK), 0, on, sc, sb, b); else hipLaunchKernelGGL((k_closest_scan<1, 2, 0>), grid, dim3(BLOCK), 0, on, sc, sb, b); }
-                    else { if (two) hipLaunchKernelGGL((k_closest_scan<2, 3, 0>), grid, dim3(BLOCK), 0, on, sc, sb, b); else hipLaunchKernelGGL((k_closest_scan<1, 3, 0>), grid, dim3(BLOCK), 0, on, sc, sb, b); }
-                } else {
-                    if (eye_rays) { if (two) hipLaunchKernelGGL((k_closest_scan<2, 2, 1>), grid, dim3(BLOCK), 0, on, sc, sb, b); else hipLaunchKernelGGL((k_closest_scan<1, 2, 1>), grid, dim3(BLOCK), 0, on, sc, sb, b); }
-                    else { if (two) hipLaunchKernelGGL((k_closest_scan<2, 3, 1>), grid, dim3(BLOCK), 0, on, sc, sb, b); else hipLaunchKernelGGL((k_closest_scan<1, 3, 1>), grid, dim3(BLOCK), 0, on, sc, sb, b); }
-                }
+                if (prim == 0) launch_closest_scan<0>(two, b == 0, grid, on, sc, sb, b);
+                else if (prim == 1) launch_closest_scan<1>(two, b == 0, grid, on, sc, sb, b);
+                else launch_closest_scan<2>(two, b == 0, grid, on, sc, sb, b);
             };
             timed(timer, 0, on, [&] {
                 if (sc.n_tri) {
                     if (!filter) hipLaunchKernelGGL((k_closest_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
                     else hierarchy_scan(0);
                 }
-                if (sc.n_sph) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
+                if (sc.n_sph) {
+                    if (!filter) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
+                    else hierarchy_scan(2);
+                }
                 if (sc.n_ell) {
                     if (!filter) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
                     else hierarchy_scan(1);
@@ -2249,15 +2375,11 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
             });
         };
         auto shadow_scan = [&](const State& sb, int prim, bool point_lights, uint32_t n, uint32_t b, uint32_t first_light, uint32_t group_first) {
-            const bool two = (prim == 0 ? sc.th : sc.eh).n_tops > TOPS_FOR_TWO_RAYS;
+            const bool two = hierarchy_of(sc, prim).n_tops > TOPS_FOR_TWO_RAYS;
             const dim3 grid(blocks_for(two ? 2 : 1), n);
-            if (prim == 0) {
-                if (point_lights) { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 2, 0>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 2, 0>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, group_first); }
-                else { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 3, 0>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 3, 0>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, group_first); }
-            } else {
-                if (point_lights) { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 2, 1>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 2, 1>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, group_first); }
-                else { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 3, 1>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 3, 1>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, group_first); }
-            }
+            if (prim == 0) launch_shadow_scan<0>(two, point_lights, grid, stream, sc, sb, b, first_light, group_first);
+            else if (prim == 1) launch_shadow_scan<1>(two, point_lights, grid, stream, sc, sb, b, first_light, group_first);
+            else launch_shadow_scan<2>(two, point_lights, grid, stream, sc, sb, b, first_light, group_first);
         };
 
         // Per bounce: closest-hit scans -> k_hit (which also writes the reflected ray) -> list compaction ->
@@ -2297,7 +2419,13 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                                 if (n_pt) shadow_scan(sb, 0, true, n_pt, b, l0 + n_dir, l0);
                             }
                         }
-                        if (sc.n_sph) hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, sb, b, l0, l0);
+                        if (sc.n_sph) {
+                            if (!filter) hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, sb, b, l0, l0);
+                            else {
+                                if (n_dir) shadow_scan(sb, 2, false, 1, b, l0, l0);
+                                if (n_pt) shadow_scan(sb, 2, true, n_pt, b, l0 + n_dir, l0);
+                            }
+                        }
                         if (sc.n_ell) {
                             if (!filter) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, sb, b, l0, l0);
                             else {
@@ -2433,6 +2561,19 @@ void ellipsoid_centroids(const float* fwd8, const float* inv8, uint32_t nb, std:
     }
 }
 
+// centres of the spheres in scan order (Sphere8: x[8], y[8], z[8], radius[8])
+void sphere_centroids(const float* sph8, uint32_t nb, std::vector<float>& centroid, std::vector<uint8_t>& good) {
+    const uint32_t n = 8u * nb;
+    centroid.assign(static_cast<size_t>(n) * 3, 0.0f);
+    good.assign(n, 0);
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t j = k / nb, i = k % nb;
+        const float* p = sph8 + static_cast<size_t>(i) * 32 + j;
+        good[k] = std::isfinite(p[0]) && std::isfinite(p[8]) && std::isfinite(p[16]) && std::isfinite(p[24]);
+        if (good[k]) for (int q = 0; q < 3; ++q) centroid[static_cast<size_t>(k) * 3 + q] = p[q * 8];
+    }
+}
+
 template <typename T>
 int upload(rt_scene* s, const T* host, size_t count, T** dev) {
     *dev = nullptr;
@@ -2492,7 +2633,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     if (desc->n_triangle8 > (1u << 26) || desc->n_sphere8 > (1u << 26) || desc->n_ellipsoid8 > (1u << 26)) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^29 primitives of one kind");
     if (desc->n_triangles > desc->n_triangle8 * 8 || desc->n_spheres > desc->n_sphere8 * 8 || desc->n_ellipsoids > desc->n_ellipsoid8 * 8) return rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: more materials than primitive slots");
     if (desc->n_point_lights > 4096) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 4096 point lights");
-    if (desc->n_triangle8 > (1u << 21) || desc->n_ellipsoid8 > (1u << 21)) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^24 triangle or ellipsoid slots");
+    if (desc->n_triangle8 > (1u << 21) || desc->n_sphere8 > (1u << 21) || desc->n_ellipsoid8 > (1u << 21)) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^24 slots of one primitive kind");
     rt_scene* s = new rt_scene();
     auto fail = [&](int rc) { rt_scene_destroy(s); return rc; };
     DevScene& d = s->dev;
@@ -2538,12 +2679,12 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
         hipLaunchKernelGGL(k_prep_ellipsoid_lights, dim3(ceil_div(d.n_ell, BLOCK)), dim3(BLOCK), 0, stream, ell, d.n_ell, raw_pl, static_cast<uint32_t>(desc->n_point_lights), ell_light);
 
     // bounding records (see Hierarchy): cluster order on the host, leaf records per kind, then the two levels above
-    std::vector<uint32_t> orders[2];   // stay alive until the stream has been synchronised below
+    std::vector<uint32_t> orders[3];   // stay alive until the stream has been synchronised below
     const size_t n_pl = desc->n_point_lights;
-    for (int prim = 0; prim < 2; ++prim) {
-        Hierarchy& h = prim == 0 ? d.th : d.eh;
-        rt_scene::EyeRecords& eye = prim == 0 ? s->eye_tri : s->eye_ell;
-        h.n = prim == 0 ? d.n_tri : d.n_ell;
+    for (int prim = 0; prim < 3; ++prim) {
+        Hierarchy& h = prim == 0 ? d.th : (prim == 1 ? d.eh : d.sh);
+        rt_scene::EyeRecords& eye = prim == 0 ? s->eye_tri : (prim == 1 ? s->eye_ell : s->eye_sph);
+        h.n = prim == 0 ? d.n_tri : (prim == 1 ? d.n_ell : d.n_sph);
         h.n_clusters = ceil_div(h.n, CLUSTER);
         h.n_tops = ceil_div(h.n_clusters, CLUSTER);
         if (h.n == 0) continue;
@@ -2552,9 +2693,12 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
         if (prim == 0) {
             if (!desc->triangle8s) return fail(rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: triangle8s is null"));
             triangle_centroids(desc->triangle8s, d.tri_nb, centroid, good);
-        } else {
+        } else if (prim == 1) {
             if (!desc->ellipsoid8_transforms || !desc->ellipsoid8_inverse_transforms) return fail(rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: ellipsoid transforms are null"));
             ellipsoid_centroids(desc->ellipsoid8_transforms, desc->ellipsoid8_inverse_transforms, d.ell_nb, centroid, good);
+        } else {
+            if (!desc->sphere8s) return fail(rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: sphere8s is null"));
+            sphere_centroids(desc->sphere8s, d.sph_nb, centroid, good);
         }
         orders[prim] = cluster_order(centroid, good);
         uint32_t* k_of;
@@ -2580,14 +2724,16 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
             d.trif_pos = trif_pos;
         }
         if (prim == 0) hipLaunchKernelGGL(k_prep_sphere, leaf_grid, dim3(BLOCK), 0, stream, tri, h.k_of, h.n, d.origin_bound, leaf_sphere);
-        else hipLaunchKernelGGL(k_prep_ell_sphere, leaf_grid, dim3(BLOCK), 0, stream, ell, h.k_of, h.n, d.origin_bound, leaf_sphere);
+        else if (prim == 1) hipLaunchKernelGGL(k_prep_ell_sphere, leaf_grid, dim3(BLOCK), 0, stream, ell, h.k_of, h.n, d.origin_bound, leaf_sphere);
+        else hipLaunchKernelGGL(k_prep_sph_sphere, leaf_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(sph), h.k_of, h.n, d.origin_bound, leaf_sphere);
         hipLaunchKernelGGL(k_prep_cluster_sphere, cl_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(leaf_sphere), h.n, h.n_clusters, d.origin_bound, cl_sphere);
         hipLaunchKernelGGL(k_prep_cluster_sphere, top_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(cl_sphere), h.n_clusters, h.n_tops, d.origin_bound, top_sphere);
         for (size_t l = 0; l < n_pl; ++l) {
             const float* L = desc->point_light_sources + l * 6;
             float4* leaf = leaf_light + l * h.n;
             if (prim == 0) hipLaunchKernelGGL(k_prep_cone, leaf_grid, dim3(BLOCK), 0, stream, tri, h.k_of, h.n, L[0], L[1], L[2], d.origin_bound, 1, leaf);
-            else hipLaunchKernelGGL(k_prep_ell_cone, leaf_grid, dim3(BLOCK), 0, stream, ell, h.k_of, h.n, L[0], L[1], L[2], d.origin_bound, 1, leaf);
+            else if (prim == 1) hipLaunchKernelGGL(k_prep_ell_cone, leaf_grid, dim3(BLOCK), 0, stream, ell, h.k_of, h.n, L[0], L[1], L[2], d.origin_bound, 1, leaf);
+            else hipLaunchKernelGGL(k_prep_sph_cone, leaf_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(sph), h.k_of, h.n, L[0], L[1], L[2], d.origin_bound, 1, leaf);
             hipLaunchKernelGGL(k_prep_cluster_cone, cl_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(leaf), h.n, h.n_clusters, cl_light + l * h.n_clusters);
             hipLaunchKernelGGL(k_prep_cluster_cone, top_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(cl_light + l * h.n_clusters), h.n_clusters, h.n_tops, top_light + l * h.n_tops);
         }

@@ -21,11 +21,13 @@ def _fmt(a):
 
 
 def write_scene(path, n_triangles=1_000_000, n_ellipsoids=10_000, n_lights=8, width=3840, height=2160,
-                maxdepth=2, seed=1, extent=10.0, edge=0.15, materials_every=1000, ell_scale=(0.05, 0.3)):
+                maxdepth=2, seed=1, extent=10.0, edge=0.15, materials_every=1000, ell_scale=(0.05, 0.3),
+                n_spheres=0, sphere_radius=(0.05, 0.3)):
     """Writes the scene; returns the path.  Deterministic in its arguments."""
     rng_t = np.random.Generator(np.random.PCG64(seed))
     rng_e = np.random.Generator(np.random.PCG64(seed + 1))
     rng_m = np.random.Generator(np.random.PCG64(seed + 2))
+    rng_s = np.random.Generator(np.random.PCG64(seed + 3))
     lines = []
     add = lines.append
     add("# synthetic scene: %d triangles, %d ellipsoids, %d point lights, seed %d" % (n_triangles, n_ellipsoids, n_lights, seed))
@@ -84,6 +86,13 @@ def write_scene(path, n_triangles=1_000_000, n_ellipsoids=10_000, n_lights=8, wi
         lines.append("scale %.6f %.6f %.6f" % tuple(sc))
         lines.append("sphere 0 0 0 1")
         lines.append("popTransform")
+
+    # true spheres (no transform in force): centre uniform in the cube, radius uniform in sphere_radius
+    for g in range(n_spheres):
+        if g % materials_every == 0:
+            lines.extend(material())
+        c = rng_s.uniform(-extent, extent, 3)
+        lines.append("sphere %.6f %.6f %.6f %.6f" % (c[0], c[1], c[2], rng_s.uniform(sphere_radius[0], sphere_radius[1])))
 
     tmp = path + ".tmp%d" % os.getpid()
     with open(tmp, "w") as f:

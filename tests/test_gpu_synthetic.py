@@ -1,4 +1,4 @@
-"""Stress of the pre-tests on random triangle soups with rotated ellipsoids and eight point lights
+"""Stress of the pre-tests on random triangle soups with rotated ellipsoids, spheres and eight point lights
 (raytracer_amd/synth.py, the generator of the benchmark's synthetic scene, at a small size).
 
 * the pre-tested scan must be invisible: same image and ids as RT_FLAG_NO_FILTER (every test
@@ -23,10 +23,15 @@ CASES = [
     dict(n_triangles=64, n_ellipsoids=2000, width=192, height=108, maxdepth=2, seed=8, ell_scale=(0.01, 0.05)),          # small far ellipsoids: the noise term of their bounds matters
     dict(n_triangles=64, n_ellipsoids=1000, width=192, height=108, maxdepth=2, seed=9, ell_scale=(0.002, 0.02)),         # so small that the bounds give up (keep-all records)
     dict(n_triangles=0, n_ellipsoids=700, width=160, height=96, maxdepth=3, seed=10, ell_scale=(0.3, 1.2)),              # no triangles at all; big overlapping ellipsoids
+    dict(n_triangles=64, n_ellipsoids=0, n_spheres=3000, width=256, height=144, maxdepth=3, seed=12),                    # sphere bounds, closest and shadow
+    dict(n_triangles=0, n_ellipsoids=0, n_spheres=1500, width=192, height=108, maxdepth=2, seed=13, sphere_radius=(0.002, 0.03)),   # small far spheres: the noise term of their bounds
+    dict(n_triangles=0, n_ellipsoids=0, n_spheres=900, width=160, height=96, maxdepth=5, seed=14, sphere_radius=(0.4, 1.5)),        # overlapping spheres: origins inside spheres, distances below the tolerance
+    dict(n_triangles=5000, n_ellipsoids=500, n_spheres=1003, width=192, height=108, maxdepth=3, seed=15),                # all three kinds; a last Sphere8 with padding lanes
 ]
 
 
-@pytest.mark.parametrize("kw", CASES, ids=["soup20k", "bigtris", "tinytris", "ellipsoids", "small_ellipsoids", "tiny_ellipsoids", "only_ellipsoids"])
+@pytest.mark.parametrize("kw", CASES, ids=["soup20k", "bigtris", "tinytris", "ellipsoids", "small_ellipsoids", "tiny_ellipsoids", "only_ellipsoids",
+                                            "spheres", "small_spheres", "big_spheres", "all_kinds"])
 def test_pretests_are_invisible_and_match_oracle(gpu, oracle, tmp_path, kw):
     fi = gpu.FileInfo(synth.ensure_scene_file(directory=str(tmp_path), **kw))
     cam = fi.camera()
