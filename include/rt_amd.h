@@ -96,7 +96,9 @@ typedef struct rt_render_params {
 #define RT_TILE 16u
 #define RT_SAMPLES_PER_PIXEL 16u  /* SQRT_SAMPLES_PER_PIXEL^2, render_work_queue.cpp:24-29 */
 
-#define RT_FLAG_NO_FILTER 1u      /* run every ray-triangle test through the full test; no conservative pre-test */
+#define RT_FLAG_NO_FILTER 1u      /* run every ray-primitive test through the full test; no bounding hierarchy, no conservative pre-test */
+#define RT_FLAG_WALK_ALL  2u      /* walk the bounding hierarchy of every primitive kind, also of kinds so small that the
+                                     library would scan them by brute force (same results; for tests and tuning) */
 
 /* Primary-hit id of one sample, as stored in the id buffer. */
 #define RT_ID_KIND_TRIANGLE  0u

@@ -33,6 +33,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -349,6 +350,17 @@ DEV bool sphere_keeps(V3 d, V3 m, float along, float4 c) {
     const float q = fma_(vz, vz, fma_(vy, vy, vx * vx));
     const float u = vdot(xyz(c), d) - along;
     return !(q > c.w) && !(u < 0.0f && u * u > c.w);
+}
+// The same with the radius enlarged by `grow` (>= 0): (sqrt(r^2) + grow)^2 = r^2 + grow (grow + 2 sqrt(r^2)); the
+// approximate square root (1 ulp) is covered by the factor 2.0002.  grow = 0 gives sphere_keeps exactly.
+DEV bool sphere_keeps_grown(V3 d, V3 m, float along, float4 c, float grow) {
+    const float vx = fma_(c.y, d.z, fma_(-c.z, d.y, -m.x));
+    const float vy = fma_(c.z, d.x, fma_(-c.x, d.z, -m.y));
+    const float vz = fma_(c.x, d.y, fma_(-c.y, d.x, -m.z));
+    const float q = fma_(vz, vz, fma_(vy, vy, vx * vx));
+    const float u = vdot(xyz(c), d) - along;
+    const float rr = fma_(grow, fma_(2.0002f, __builtin_amdgcn_sqrtf(c.w), grow), c.w);
+    return !(q > rr) && !(u < 0.0f && u * u > rr);
 }
 DEV float sphere_along(V3 o, V3 d, float origin_bound) { return vdot(o, d) - SPHERE_BEHIND_SLACK * origin_bound; }
 
@@ -910,14 +922,26 @@ __global__ void __launch_bounds__(BLOCK) k_prep_ell_cone(const float4* __restric
 // hit_sphere accepts when r*r - (oc.oc - (oc.d)^2) >= 0 in binary32, oc = c - o.  With |oc| <= D the
 // roundings of oc (relative 2^-24 per component), of the two dot products, of the square and of
 // the difference move perp2 by less than 11 eps D^2, and a direction longer than 1 lowers it by
-// (|d|^2 - 1) (oc.d)^2 <= SPH_DIR_SLACK * D^2: reflected directions are not renormalised, and the
-// scans keep every sphere for a wave that holds a ray with |d|^2 beyond 1 + SPH_DIR_SLACK (as
-// evaluated: SPH_DIR_CHECK).  A line the test accepts therefore passes within
-// sqrt(r^2 + (16 eps + SPH_DIR_SLACK) D^2) of the centre.  The distance the test returns can be negative (origin
+// (|d|^2 - 1) (oc.d)^2: reflected directions are not renormalised.  The records allow for
+// |d|^2 <= 1 + SPH_DIR_SLACK: a line the test accepts then passes within
+// sqrt(r^2 + (16 eps + SPH_DIR_SLACK) D^2) of the centre.  A ray whose direction is longer than that
+// (as evaluated: SPH_DIR_CHECK) has every radius enlarged by sphere_growth() in the scan of its
+// bounce (sphere_keeps_grown); where that is not done (cone records, shadow rays: directions
+// normalised a moment ago) a wave that holds such a ray keeps every sphere.  The distance the test returns can be negative (origin
 // inside the sphere); such a sphere is neither behind the origin for sphere_keeps nor outside a
 // cone of directions through the origin, so the pre-tests need no special case for it.
 constexpr float SPH_DIR_SLACK = 32.0f * 5.9604644775390625e-8f;
 constexpr float SPH_DIR_CHECK = 1.0f + 28.0f * 5.9604644775390625e-8f;   // |d|^2 as evaluated carries up to 3 eps
+// Enlargement of every sphere radius for a ray with direction d (not normalised), origins and centres
+// within max-norm B of 0: the excess e of |d|^2 over what the records allow adds e |oc|^2 <= 12 B^2 e
+// to the squared radius the test accepts.  The records' radius is reach + s with s the roundings of
+// the pre-test itself (s < 400 eps B): (sqrt(reach^2 + x) + s)^2 <= (reach + s)^2 + 1.5 x + 2 s^2,
+// so growing the record's radius by sqrt(1.5 x + 2 s^2) is enough.
+DEV float sphere_growth(V3 d, float B) {
+    const float e = vdot(d, d) - SPH_DIR_CHECK;
+    if (!(e > 0.0f)) return 0.0f;
+    return __builtin_sqrtf(fma_(e * 18.0018f, B * B, 1.2e-9f * (B * B))) * 1.0001f;
+}
 __device__ double sph_reach(double r, double D) {
     const double eps = 5.9604644775390625e-8;   // 2^-24
     return sqrt(r * r * (1.0 + 4.0 * eps) + (16.0 * eps + SPH_DIR_SLACK) * D * D) * (1.0 + 1.0e-6) + 4.0 * eps * D;
@@ -1307,9 +1331,11 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     uint32_t slot[R];
     bool valid[R];
     V3 d[R], moment[R];
-    float along[R];
+    float along[R], grow[R];
     Packet packet;
     bool unsafe = false;    // an origin outside the bound the sphere records were built for: keep everything
+    bool too_long = false;  // a direction longer than the bounds of the spheres allow for: likewise
+    constexpr bool GROWN = MODE == 3 && PRIM == 2;   // spheres, rays with their own origin: radii grow with the length of the direction
     {
         V3 o[R];
 #pragma unroll
@@ -1319,16 +1345,24 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             slot[r] = list_in[valid[r] ? i : base];
             o[r] = {st.ox[slot[r]], st.oy[slot[r]], st.oz[slot[r]]};
             d[r] = {st.dx[slot[r]], st.dy[slot[r]], st.dz[slot[r]]};
-            if (PRIM == 2) unsafe |= !(vdot(d[r], d[r]) <= SPH_DIR_CHECK);   // the sphere bounds allow for this much extra length only
+            if (PRIM == 2 && !GROWN) too_long |= !(vdot(d[r], d[r]) <= SPH_DIR_CHECK);   // the sphere bounds allow for this much extra length only
+            grow[r] = GROWN ? sphere_growth(d[r], sc.origin_bound) : 0.0f;
             if (MODE == 3) d[r] = normalise(d[r]);   // pre-test copy only: reflected directions drift off unit length
             moment[r] = scross(o[r], d[r]);
             along[r] = sphere_along(o[r], d[r], sc.origin_bound);
             unsafe |= !(fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z))) <= sc.origin_bound);
             wave_slots[r * 64 + lane] = slot[r];
         }
-        packet = uniform_packet(make_packet<R>(d, MODE == 3 ? o : nullptr, valid));
+        packet = make_packet<R>(d, MODE == 3 ? o : nullptr, valid);
+        if (GROWN) {   // a larger ball of origins is the same as larger spheres
+            float g = 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) g = fmaxf(g, valid[r] ? grow[r] : 0.0f);
+            packet.rho += wave_max(g);
+        }
+        packet = uniform_packet(packet);
     }
-    const bool keep_all = (MODE == 3 || PRIM == 2) && __any(unsafe);
+    const bool keep_all = (MODE == 3 && __any(unsafe)) || (PRIM == 2 && __any(too_long));
     const float4* __restrict__ top_stream = MODE == 2 ? h.top_eye : h.top_sphere;
     const float4* __restrict__ cluster_stream = MODE == 2 ? h.cl_eye : h.cl_sphere;
     const float4* __restrict__ leaf_stream = MODE == 2 ? h.leaf_eye : h.leaf_sphere;
@@ -1385,6 +1419,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             const uint32_t s = wave_slots[e >> 24], first = (e & NODE_MASK) * CLUSTER;
             const V3 o{st.ox[s], st.oy[s], st.oz[s]};
             V3 dd{st.dx[s], st.dy[s], st.dz[s]};
+            const float gr = GROWN ? sphere_growth(dd, sc.origin_bound) : 0.0f;
             if (MODE == 3) dd = normalise(dd);
             const V3 mm = scross(o, dd);
             const float al = sphere_along(o, dd, sc.origin_bound);
@@ -1398,7 +1433,8 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
                 uint32_t keep_bits = 0;
 #pragma unroll
                 for (int u = 0; u < WALK_BATCH; ++u) {
-                    const bool keep = active && first + t0 + u <= last && ((MODE == 2 ? cone_keeps(dd, rec[u]) : sphere_keeps(dd, mm, al, rec[u])) || keep_all);
+                    const bool keep = active && first + t0 + u <= last &&
+                                      ((MODE == 2 ? cone_keeps(dd, rec[u]) : (GROWN ? sphere_keeps_grown(dd, mm, al, rec[u], gr) : sphere_keeps(dd, mm, al, rec[u]))) || keep_all);
                     keep_bits |= keep ? 1u << u : 0u;
                 }
 #pragma nounroll
@@ -1429,7 +1465,8 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             const float4 c = readlane4(mine, bit);
             uint32_t keep_bits = 0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) keep_bits |= ((MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], along[r], c)) || keep_all) && valid[r] ? 1u << r : 0u;
+            for (int r = 0; r < R; ++r)
+                keep_bits |= ((MODE == 2 ? cone_keeps(d[r], c) : (GROWN ? sphere_keeps_grown(d[r], moment[r], along[r], c, grow[r]) : sphere_keeps(d[r], moment[r], along[r], c))) || keep_all) && valid[r] ? 1u << r : 0u;
             if (__any(keep_bits != 0u)) {
                 if (q0_count + PUSH_MAX > QCAP) drain0();
                 push_bits(q0, q0_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
@@ -2130,6 +2167,18 @@ constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;   // brute-force scans
 // is best while the top level is short (scene7: 391 top nodes).  Walking a long top level once per
 // wave costs more than that, so big scenes (the synthetic one: 3907 top nodes) take two.
 constexpr uint32_t TOPS_FOR_TWO_RAYS = 1024;
+// A kind with at most this many slots is scanned by brute force even in the default mode: the walk of
+// a hierarchy costs more than it saves there (measured crossover: 32 to 64 slots for every kind;
+// scene6, 40 + 8 + 8 slots and 1.15 G rays at 3840x2160: 208 ms walking, 141 ms brute force).
+// RT_AMD_BRUTE_BELOW in the environment overrides it (tuning); RT_FLAG_WALK_ALL walks regardless.
+constexpr uint32_t BRUTE_FORCE_BELOW = 64;
+uint32_t brute_force_below() {
+    static const uint32_t value = [] {
+        const char* e = std::getenv("RT_AMD_BRUTE_BELOW");
+        return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : BRUTE_FORCE_BELOW;
+    }();
+    return value;
+}
 constexpr uint32_t DEFAULT_CHUNK_TILES = 32768;   // 134 M samples, 18.8 GB of ray state: a 3840x2160 frame in one chunk (long launches hide the tail of the slowest waves)
 constexpr uint32_t MAX_BOUNCES = 62;
 constexpr uint32_t MIN_LANE_TILES = 256;   // a frame is cut into chunks of at least this many tiles, one per lane
@@ -2163,6 +2212,7 @@ struct rt_scene {
     mutable EyeRecords eye_tri, eye_ell, eye_sph;
     mutable float eye[3] = {0, 0, 0};
     mutable bool eye_valid = false;
+    bool directional_is_unit = true;   // |direction|^2 <= 1 + 20 * 2^-24: the shadow scans toward it may use the pre-tests
 };
 
 namespace {
@@ -2317,6 +2367,9 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
 
     const uint32_t depth = static_cast<uint32_t>(prm->max_bounce_count);
     const bool filter = (prm->flags & RT_FLAG_NO_FILTER) == 0;
+    // per kind (0 triangles, 1 ellipsoids, 2 spheres): walk its hierarchy, or scan it by brute force
+    const uint32_t below = (prm->flags & RT_FLAG_WALK_ALL) ? 0u : brute_force_below();
+    const bool walk[3] = {filter && sc.th.n > below, filter && sc.eh.n > below, filter && sc.sh.n > below};
     if (n_lanes > 1) {   // the other lanes start when the eye records and the cleared counters are ready
         HIP_TRY(hipEventRecord(g_lib.lanes_fork, g_lib.lanes[0].stream));
         for (uint32_t l = 1; l < n_lanes; ++l) HIP_TRY(hipStreamWaitEvent(g_lib.lanes[l].stream, g_lib.lanes_fork, 0));
@@ -2361,15 +2414,15 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
             };
             timed(timer, 0, on, [&] {
                 if (sc.n_tri) {
-                    if (!filter) hipLaunchKernelGGL((k_closest_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
+                    if (!walk[0]) hipLaunchKernelGGL((k_closest_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
                     else hierarchy_scan(0);
                 }
                 if (sc.n_sph) {
-                    if (!filter) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
+                    if (!walk[2]) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
                     else hierarchy_scan(2);
                 }
                 if (sc.n_ell) {
-                    if (!filter) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
+                    if (!walk[1]) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
                     else hierarchy_scan(1);
                 }
             });
@@ -2411,27 +2464,22 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                     // the directional light, if it is in this group, is light 0; the rest are point lights
                     const uint32_t n_dir = (l0 == 0 && sc.has_directional) ? 1u : 0u;
                     const uint32_t n_pt = group - n_dir;
+                    // brute-force shadow scan of one kind toward lights first.. (n of them)
+                    auto brute_force = [&](int prim, uint32_t n, uint32_t first_light) {
+                        const dim3 grid(scan_blocks, n);
+                        if (prim == 0) hipLaunchKernelGGL((k_shadow_scan<RAYS_PER_LANE, 0, 0>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
+                        else if (prim == 1) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
+                        else hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
+                    };
                     timed(timer, 1, stream, [&] {
-                        if (sc.n_tri) {
-                            if (!filter) hipLaunchKernelGGL((k_shadow_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, sb, b, l0, l0);
-                            else {
-                                if (n_dir) shadow_scan(sb, 0, false, 1, b, l0, l0);
-                                if (n_pt) shadow_scan(sb, 0, true, n_pt, b, l0 + n_dir, l0);
-                            }
-                        }
-                        if (sc.n_sph) {
-                            if (!filter) hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, sb, b, l0, l0);
-                            else {
-                                if (n_dir) shadow_scan(sb, 2, false, 1, b, l0, l0);
-                                if (n_pt) shadow_scan(sb, 2, true, n_pt, b, l0 + n_dir, l0);
-                            }
-                        }
-                        if (sc.n_ell) {
-                            if (!filter) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, dim3(scan_blocks, group), dim3(BLOCK), 0, stream, sc, sb, b, l0, l0);
-                            else {
-                                if (n_dir) shadow_scan(sb, 1, false, 1, b, l0, l0);
-                                if (n_pt) shadow_scan(sb, 1, true, n_pt, b, l0 + n_dir, l0);
-                            }
+                        const uint32_t count[3] = {sc.n_tri, sc.n_ell, sc.n_sph};
+                        for (int prim = 0; prim < 3; ++prim) {
+                            if (count[prim] == 0) continue;
+                            if (!walk[prim]) { brute_force(prim, group, l0); continue; }
+                            // the pre-tests need a direction of unit length; the directional light's is the caller's
+                            if (n_dir && scene->directional_is_unit) shadow_scan(sb, prim, false, 1, b, l0, l0);
+                            else if (n_dir) brute_force(prim, 1, l0);
+                            if (n_pt) shadow_scan(sb, prim, true, n_pt, b, l0 + n_dir, l0);
                         }
                     });
                     hipLaunchKernelGGL(k_shade, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, sb, b, l0, group, (l0 + group == sc.n_lights) ? 1u : 0u);
@@ -2745,6 +2793,8 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     if (d.has_directional) {
         const float* L = desc->directional_light;
         lights.insert(lights.end(), {0.0f, L[0], L[1], L[2], L[3], L[4], L[5], 0.0f});
+        const double len2 = static_cast<double>(L[0]) * L[0] + static_cast<double>(L[1]) * L[1] + static_cast<double>(L[2]) * L[2];
+        s->directional_is_unit = len2 <= 1.0 + 20.0 * 5.9604644775390625e-8;   // shorter is harmless: every pre-test only gets weaker
     }
     for (uint64_t l = 0; l < desc->n_point_lights; ++l) {
         const float* L = desc->point_light_sources + l * 6;

@@ -40,9 +40,12 @@ def _render_both(gpu, oracle, name, rect, **overrides):
     return g, o
 
 
+@pytest.mark.parametrize("walk_all", [False, True], ids=["default", "walk_all"])
 @pytest.mark.parametrize("name,rect", CASES, ids=[c[0] for c in CASES])
-def test_image_and_ids_match_oracle(gpu, oracle, name, rect):
-    g, o = _render_both(gpu, oracle, name, rect)
+def test_image_and_ids_match_oracle(gpu, oracle, name, rect, walk_all):
+    # default: kinds of at most 64 slots are scanned by brute force; walk_all: every kind through its bounding hierarchy
+    from raytracer_amd import abi
+    g, o = _render_both(gpu, oracle, name, rect, flags=abi.RT_FLAG_WALK_ALL if walk_all else 0)
     id_diff = int((g["ids"] != o["ids"]).sum())
     px_diff = int((g["rgb"] != o["rgb"]).any(axis=2).sum())
     max_lsb = int(np.abs(g["rgb"].astype(int) - o["rgb"].astype(int)).max())
@@ -62,11 +65,12 @@ def test_pretest_does_not_change_results(gpu, name):
     fi = gpu.FileInfo(scene_path(name))
     cam = fi.camera()
     scene = gpu.Scene(fi.scene_desc)
-    a = scene.render(cam, fi.params(), want_ids=True)
+    a = scene.render(cam, fi.params(flags=abi.RT_FLAG_WALK_ALL), want_ids=True)
     b = scene.render(cam, fi.params(flags=abi.RT_FLAG_NO_FILTER), want_ids=True)
+    c = scene.render(cam, fi.params(), want_ids=True)
     scene.close()
-    assert np.array_equal(a["ids"], b["ids"])
-    assert np.array_equal(a["rgb"], b["rgb"])
+    assert np.array_equal(a["ids"], b["ids"]) and np.array_equal(c["ids"], b["ids"])
+    assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(c["rgb"], b["rgb"])
     assert b["stats"].full_tests == 0
     if fi.scene_desc.n_triangles:
         assert 0 < a["stats"].full_tests
@@ -86,3 +90,26 @@ def test_chunking_does_not_change_results(gpu, name):
         for f in ("samples", "culled", "closest_rays", "hits", "shadow_rays", "shadow_blocked"):
             assert getattr(part["stats"], f) == getattr(whole["stats"], f), (chunk_tiles, f)
     scene.close()
+
+
+@pytest.mark.parametrize("name", ["scene5", "scene6"])   # 1000 spheres / 34 triangles, 3 spheres, an ellipsoid; a directional and a point light each
+@pytest.mark.parametrize("factor", [1.0005, 0.9, 3.0])
+def test_directional_light_that_is_not_of_unit_length(gpu, factor, name):
+    """The parser normalises the light's direction, a caller of the C ABI need not: the pre-tests
+    of the shadow scans assume unit length and must step aside (same results as the full tests)."""
+    from raytracer_amd import abi
+    fi = gpu.FileInfo(scene_path(name))
+    assert fi.scene_desc.has_directional_light
+    for i in range(3):
+        fi.scene_desc.directional_light[i] *= factor
+    cam = fi.camera()
+    rect = dict(rect_x0=160, rect_y0=120, rect_w=320, rect_h=160)
+    scene = gpu.Scene(fi.scene_desc)
+    a = scene.render(cam, fi.params(flags=abi.RT_FLAG_WALK_ALL, **rect), want_ids=True)
+    b = scene.render(cam, fi.params(flags=abi.RT_FLAG_NO_FILTER, **rect), want_ids=True)
+    scene.close()
+    assert np.array_equal(a["ids"], b["ids"])
+    assert np.array_equal(a["rgb"], b["rgb"])
+    for f in ("closest_rays", "hits", "shadow_rays", "shadow_blocked"):
+        assert getattr(a["stats"], f) == getattr(b["stats"], f), f
+    assert a["stats"].shadow_blocked > 0

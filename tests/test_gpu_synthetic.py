@@ -36,10 +36,11 @@ def test_pretests_are_invisible_and_match_oracle(gpu, oracle, tmp_path, kw):
     fi = gpu.FileInfo(synth.ensure_scene_file(directory=str(tmp_path), **kw))
     cam = fi.camera()
     scene = gpu.Scene(fi.scene_desc)
-    a = scene.render(cam, fi.params(), want_ids=True)
+    a = scene.render(cam, fi.params(flags=abi.RT_FLAG_WALK_ALL), want_ids=True)     # every kind through its hierarchy
     b = scene.render(cam, fi.params(flags=abi.RT_FLAG_NO_FILTER), want_ids=True)
-    assert np.array_equal(a["ids"], b["ids"])
-    assert np.array_equal(a["rgb"], b["rgb"])
+    c = scene.render(cam, fi.params(), want_ids=True)                                # small kinds by brute force
+    assert np.array_equal(a["ids"], b["ids"]) and np.array_equal(c["ids"], b["ids"])
+    assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(c["rgb"], b["rgb"])
     for f in ("closest_rays", "hits", "shadow_rays", "shadow_blocked"):
         assert getattr(a["stats"], f) == getattr(b["stats"], f), f
     assert a["stats"].hits > 0 and a["stats"].shadow_blocked > 0
