@@ -94,6 +94,7 @@ struct Hierarchy {
     const float4 *leaf_eye, *leaf_light, *leaf_sphere;   // leaf_light: [point light][position]
     const float4 *cl_eye, *cl_light, *cl_sphere;
     const float4 *top_eye, *top_light, *top_sphere;
+    const float4 *leaf_box, *cl_box, *top_box;            // 2 x float4 per node: (lo, 0) (hi, 0), see box_keeps
     uint32_t n, n_clusters, n_tops;
 };
 
@@ -120,6 +121,7 @@ struct DevScene {
     float ambient[3];
     float atten[3];
     float origin_bound;   // every bounce / shadow ray starts within this max-norm distance of 0 (scene box + slack)
+    float box_bound;      // the box records hold for origins within this max-norm distance of 0 (>= origin_bound; covers the eye)
 };
 
 struct Frame {
@@ -363,6 +365,42 @@ DEV bool sphere_keeps_grown(V3 d, V3 m, float along, float4 c, float grow) {
     return !(q > rr) && !(u < 0.0f && u * u > rr);
 }
 DEV float sphere_along(V3 o, V3 d, float origin_bound) { return vdot(o, d) - SPHERE_BEHIND_SLACK * origin_bound; }
+
+// Box pre-test (slab test) for any ray: the record is an axis-aligned box that contains every hit
+// point the full tests can accept on the primitives below the node; a ray whose segment
+// [0, limit] misses the box cannot hit them.  inv = 1/d per component (approximate reciprocal,
+// 1 ulp; a zero component gives an infinity: the products are then infinities of the right sign,
+// or NaN when the origin lies on the slab's plane, which min/max drop).  Each t carries a relative
+// error below 6 * 2^-24 (difference, reciprocal, product), so an interval that is non-empty in exact
+// arithmetic has tmin <= tmax * (1 + 2e-6) as evaluated; the sign of tmax is exact.  A box of
+// infinities keeps every ray; NaN keeps the ray.
+struct BoxRay { V3 o, inv; float limit; };
+DEV BoxRay make_box_ray(V3 o, V3 d, float limit) {
+    return BoxRay{o, V3{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)}, limit};
+}
+DEV bool box_keeps(const BoxRay& r, float4 lo, float4 hi) {
+    const float ax = (lo.x - r.o.x) * r.inv.x, bx = (hi.x - r.o.x) * r.inv.x;
+    const float ay = (lo.y - r.o.y) * r.inv.y, by = (hi.y - r.o.y) * r.inv.y;
+    const float az = (lo.z - r.o.z) * r.inv.z, bz = (hi.z - r.o.z) * r.inv.z;
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    const float far = __builtin_fminf(tmax, r.limit) * 1.000002f;
+    return !(tmax < 0.0f) && !(tmin > far);
+}
+// The same with the box enlarged by `grow` (>= 0) on every side.
+DEV bool box_keeps_grown(const BoxRay& r, float4 lo, float4 hi, float grow) {
+    lo.x -= grow; lo.y -= grow; lo.z -= grow;
+    hi.x += grow; hi.y += grow; hi.z += grow;
+    return box_keeps(r, lo, hi);
+}
+// Bounding sphere (centre, radius^2) of a box record, for the per-wave test (packet_sphere_keeps)
+DEV float4 box_sphere(float4 lo, float4 hi) {
+    const V3 c{0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+    const V3 h{hi.x - c.x, hi.y - c.y, hi.z - c.z};
+    const V3 l{c.x - lo.x, c.y - lo.y, c.z - lo.z};
+    const V3 e{fmaxf(h.x, l.x), fmaxf(h.y, l.y), fmaxf(h.z, l.z)};
+    return make_float4(c.x, c.y, c.z, vdot(e, e) * 1.00001f);
+}
 
 // Per-wave ("packet") pre-test, ahead of cone_keeps / sphere_keeps.  A wave's rays are neighbours
 // in the image, so they fit in a narrow bound: a cone of directions (unit axis A, cosine cw of the
@@ -802,6 +840,72 @@ __global__ void __launch_bounds__(BLOCK) k_prep_ellipsoids(const float* __restri
     }
 }
 
+// Box records (box_keeps).  Leaves: the box of everything the full test can accept on the primitive
+// (the same regions as for the sphere records), rounded outward to binary32; clusters and top
+// nodes: the union of their children, which is exact.
+DEV void store_box(float4* __restrict__ out, uint32_t pos, const double* lo, const double* hi, bool ok) {
+    const float inf = __builtin_inff();
+    float4 l = make_float4(-inf, -inf, -inf, 0.0f), h = make_float4(inf, inf, inf, 0.0f);   // keeps every ray
+    if (ok && isfinite(lo[0]) && isfinite(lo[1]) && isfinite(lo[2]) && isfinite(hi[0]) && isfinite(hi[1]) && isfinite(hi[2])) {
+        l = make_float4(nextafterf(static_cast<float>(lo[0]), -inf), nextafterf(static_cast<float>(lo[1]), -inf), nextafterf(static_cast<float>(lo[2]), -inf), 0.0f);
+        h = make_float4(nextafterf(static_cast<float>(hi[0]), inf), nextafterf(static_cast<float>(hi[1]), inf), nextafterf(static_cast<float>(hi[2]), inf), 0.0f);
+    }
+    out[static_cast<size_t>(pos) * 2] = l;
+    out[static_cast<size_t>(pos) * 2 + 1] = h;
+}
+// triangles: as in k_prep_sphere, the hit point lies within delta of the triangle scaled by (1 + 3m) about its centroid
+__global__ void __launch_bounds__(BLOCK) k_prep_tri_box(const float4* __restrict__ tri, const uint32_t* __restrict__ k_of, uint32_t n_tri, float origin_bound, float4* __restrict__ out) {
+    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
+    if (pos >= n_tri) return;
+    const uint32_t k = k_of[pos];
+    const float4 t0 = tri[static_cast<size_t>(k) * 4], t1 = tri[static_cast<size_t>(k) * 4 + 1], t2 = tri[static_cast<size_t>(k) * 4 + 2], t3 = tri[static_cast<size_t>(k) * 4 + 3];
+    const double a[3] = {t0.x, t0.y, t0.z}, n[3] = {t0.w, t1.w, t2.w}, ab[3] = {t1.x, t1.y, t1.z}, ac[3] = {t2.x, t2.y, t2.z};
+    const double nn = static_cast<double>(t3.x);
+    auto max3 = [](const double* v) { return fmax(fabs(v[0]), fmax(fabs(v[1]), fabs(v[2]))); };
+    auto len3 = [](const double* v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    double lo[3] = {0.0, 0.0, 0.0}, hi[3] = {0.0, 0.0, 0.0};
+    bool ok = false;
+    if (nn > 0.0) {
+        const double eps = 5.9604644775390625e-8;   // 2^-24
+        const double B = origin_bound;
+        const double Q = max3(n) * fmax(max3(ab), max3(ac)) / nn;
+        const double edges = len3(ab) + len3(ac);
+        const double T = 2.0 * (1.7320508075688772 * (max3(a) + B) + edges);   // origin to any accepted hit, with slack
+        const double m = 2.0 * (48.0 * eps * Q * (B + T + max3(a)) + eps);
+        const double delta = 2.0 * 13.0 * eps * T;
+        ok = m < 1.0e6;
+        for (int i = 0; i < 3; ++i) {
+            const double c = a[i] + (ab[i] + ac[i]) / 3.0;
+            const double v[3] = {a[i], a[i] + ab[i], a[i] + ac[i]};
+            lo[i] = 1.0e300; hi[i] = -1.0e300;
+            for (int j = 0; j < 3; ++j) {
+                const double w = c + (1.0 + 3.0 * m) * (v[j] - c);
+                lo[i] = fmin(lo[i], w); hi[i] = fmax(hi[i], w);
+            }
+            lo[i] -= delta; hi[i] += delta;
+        }
+    }
+    store_box(out, pos, lo, hi, ok);
+}
+__global__ void __launch_bounds__(BLOCK) k_prep_cluster_box(const float4* __restrict__ member, uint32_t n_member, uint32_t n_nodes, float4* __restrict__ out) {
+    const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= n_nodes) return;
+    const uint32_t first = c * CLUSTER, count = min(CLUSTER, n_member - first);
+    const float inf = __builtin_inff();
+    float4 lo = make_float4(inf, inf, inf, 0.0f), hi = make_float4(-inf, -inf, -inf, 0.0f);
+    bool all = false;
+    for (uint32_t t = 0; t < count; ++t) {
+        const float4 l = member[static_cast<size_t>(first + t) * 2], h = member[static_cast<size_t>(first + t) * 2 + 1];
+        // NaN anywhere (not produced by the leaf kernels) would be dropped by min/max: keep every ray instead
+        if (!(l.x <= h.x) || !(l.y <= h.y) || !(l.z <= h.z)) all = true;
+        lo.x = fminf(lo.x, l.x); lo.y = fminf(lo.y, l.y); lo.z = fminf(lo.z, l.z);
+        hi.x = fmaxf(hi.x, h.x); hi.y = fmaxf(hi.y, h.y); hi.z = fmaxf(hi.z, h.z);
+    }
+    if (all) { lo = make_float4(-inf, -inf, -inf, 0.0f); hi = make_float4(inf, inf, inf, 0.0f); }
+    out[static_cast<size_t>(c) * 2] = lo;
+    out[static_cast<size_t>(c) * 2 + 1] = hi;
+}
+
 // ---- bounding records of the ellipsoids (all in double) ----
 // The full test (hit_ellipsoid / ellipsoid_blocks) maps the ray with the inverse transform
 // (rows i0..i2: linear part Ainv, translation t) and tests the unit sphere, so the solid it
@@ -918,6 +1022,25 @@ __global__ void __launch_bounds__(BLOCK) k_prep_ell_cone(const float4* __restric
     out[pos] = rec;
 }
 
+// box records of the ellipsoids: the hit point lies within ell_reach of the centre
+__global__ void __launch_bounds__(BLOCK) k_prep_ell_box(const float4* __restrict__ ell, const uint32_t* __restrict__ k_of, uint32_t n, float origin_bound, float4* __restrict__ out) {
+    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
+    if (pos >= n) return;
+    const uint32_t k = k_of[pos];
+    const EllBound b = ell_bound(ell[static_cast<size_t>(k) * 6], ell[static_cast<size_t>(k) * 6 + 1], ell[static_cast<size_t>(k) * 6 + 2]);
+    double lo[3] = {0.0, 0.0, 0.0}, hi[3] = {0.0, 0.0, 0.0};
+    bool ok = false;
+    if (b.ok) {
+        const double B = origin_bound;
+        const double c_len = sqrt(b.c[0] * b.c[0] + b.c[1] * b.c[1] + b.c[2] * b.c[2]);
+        const double D = 1.7320508075688772 * B + c_len;
+        const double r = ell_reach(b, D, B) * (1.0 + 1.0e-6);
+        ok = r < 1.0e30;
+        for (int i = 0; i < 3; ++i) { lo[i] = b.c[i] - r; hi[i] = b.c[i] + r; }
+    }
+    store_box(out, pos, lo, hi, ok);
+}
+
 // ---- bounding records of the spheres (all in double) ----
 // hit_sphere accepts when r*r - (oc.oc - (oc.d)^2) >= 0 in binary32, oc = c - o.  With |oc| <= D the
 // roundings of oc (relative 2^-24 per component), of the two dot products, of the square and of
@@ -1002,6 +1125,25 @@ __global__ void __launch_bounds__(BLOCK) k_prep_sph_cone(const float4* __restric
         }
     }
     out[pos] = rec;
+}
+
+// box records of the spheres.  The hit point o + t d of an accepted ray lies at sqrt(perp^2 + h^2) of the
+// centre, with h^2 = r^2 - perp2 as evaluated: the noise of perp2 enters twice.
+__global__ void __launch_bounds__(BLOCK) k_prep_sph_box(const float4* __restrict__ sph, const uint32_t* __restrict__ k_of, uint32_t n, float origin_bound, float4* __restrict__ out) {
+    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
+    if (pos >= n) return;
+    const float4 s = sph[k_of[pos]];
+    double lo[3] = {0.0, 0.0, 0.0}, hi[3] = {0.0, 0.0, 0.0};
+    const bool ok = sph_usable(s);
+    if (ok) {
+        const double c[3] = {s.x, s.y, s.z};
+        const double c_len = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+        const double D = 1.7320508075688772 * origin_bound + c_len;
+        const double r1 = sph_reach(fabs(static_cast<double>(s.w)), D);
+        const double r = sph_reach(r1, D);
+        for (int i = 0; i < 3; ++i) { lo[i] = c[i] - r; hi[i] = c[i] + r; }
+    }
+    store_box(out, pos, lo, hi, ok);
 }
 
 // inverse transform applied to each point light's position (ray_tracing.cpp:388), once per scene
@@ -1332,10 +1474,11 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     bool valid[R];
     V3 d[R], moment[R];
     float along[R], grow[R];
+    BoxRay box_ray[R];      // MODE 4
     Packet packet;
     bool unsafe = false;    // an origin outside the bound the sphere records were built for: keep everything
     bool too_long = false;  // a direction longer than the bounds of the spheres allow for: likewise
-    constexpr bool GROWN = MODE == 3 && PRIM == 2;   // spheres, rays with their own origin: radii grow with the length of the direction
+    constexpr bool GROWN = (MODE == 3 || MODE == 4) && PRIM == 2;   // spheres, rays of any direction length: the bounds grow with the length
     {
         V3 o[R];
 #pragma unroll
@@ -1346,14 +1489,21 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             o[r] = {st.ox[slot[r]], st.oy[slot[r]], st.oz[slot[r]]};
             d[r] = {st.dx[slot[r]], st.dy[slot[r]], st.dz[slot[r]]};
             if (PRIM == 2 && !GROWN) too_long |= !(vdot(d[r], d[r]) <= SPH_DIR_CHECK);   // the sphere bounds allow for this much extra length only
-            grow[r] = GROWN ? sphere_growth(d[r], sc.origin_bound) : 0.0f;
-            if (MODE == 3) d[r] = normalise(d[r]);   // pre-test copy only: reflected directions drift off unit length
-            moment[r] = scross(o[r], d[r]);
-            along[r] = sphere_along(o[r], d[r], sc.origin_bound);
-            unsafe |= !(fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z))) <= sc.origin_bound);
+            if (MODE == 4) {
+                box_ray[r] = make_box_ray(o[r], d[r], FLT_MAX);
+                grow[r] = GROWN ? 2.0f * sphere_growth(d[r], sc.box_bound) : 0.0f;   // twice: the hit point, not only the line (k_prep_sph_box)
+                unsafe |= !(fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z))) <= sc.box_bound);
+                d[r] = normalise(d[r]);   // for the bound of the wave
+            } else {
+                grow[r] = GROWN ? sphere_growth(d[r], sc.origin_bound) : 0.0f;
+                if (MODE == 3) d[r] = normalise(d[r]);   // pre-test copy only: reflected directions drift off unit length
+                moment[r] = scross(o[r], d[r]);
+                along[r] = sphere_along(o[r], d[r], sc.origin_bound);
+                unsafe |= !(fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z))) <= sc.origin_bound);
+            }
             wave_slots[r * 64 + lane] = slot[r];
         }
-        packet = make_packet<R>(d, MODE == 3 ? o : nullptr, valid);
+        packet = make_packet<R>(d, MODE >= 3 ? o : nullptr, valid);
         if (GROWN) {   // a larger ball of origins is the same as larger spheres
             float g = 0.0f;
 #pragma unroll
@@ -1362,10 +1512,10 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
         }
         packet = uniform_packet(packet);
     }
-    const bool keep_all = (MODE == 3 && __any(unsafe)) || (PRIM == 2 && __any(too_long));
-    const float4* __restrict__ top_stream = MODE == 2 ? h.top_eye : h.top_sphere;
-    const float4* __restrict__ cluster_stream = MODE == 2 ? h.cl_eye : h.cl_sphere;
-    const float4* __restrict__ leaf_stream = MODE == 2 ? h.leaf_eye : h.leaf_sphere;
+    const bool keep_all = (MODE >= 3 && __any(unsafe)) || (PRIM == 2 && __any(too_long));
+    const float4* __restrict__ top_stream = MODE == 2 ? h.top_eye : (MODE == 3 ? h.top_sphere : h.top_box);
+    const float4* __restrict__ cluster_stream = MODE == 2 ? h.cl_eye : (MODE == 3 ? h.cl_sphere : h.cl_box);
+    const float4* __restrict__ leaf_stream = MODE == 2 ? h.leaf_eye : (MODE == 3 ? h.leaf_sphere : h.leaf_box);
 
     // (ray, triangle) pairs: two-stage pre-test and full test, one pair per lane
     auto drain2 = [&]() {
@@ -1419,7 +1569,8 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             const uint32_t s = wave_slots[e >> 24], first = (e & NODE_MASK) * CLUSTER;
             const V3 o{st.ox[s], st.oy[s], st.oz[s]};
             V3 dd{st.dx[s], st.dy[s], st.dz[s]};
-            const float gr = GROWN ? sphere_growth(dd, sc.origin_bound) : 0.0f;
+            const BoxRay ray = make_box_ray(o, dd, FLT_MAX);
+            const float gr = GROWN ? (MODE == 4 ? 2.0f * sphere_growth(dd, sc.box_bound) : sphere_growth(dd, sc.origin_bound)) : 0.0f;
             if (MODE == 3) dd = normalise(dd);
             const V3 mm = scross(o, dd);
             const float al = sphere_along(o, dd, sc.origin_bound);
@@ -1427,15 +1578,29 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             static_assert(CLUSTER % WALK_BATCH == 0 && WALK_BATCH % 4 == 0, "the walk takes WALK_BATCH children at a time, pushed four by four");
 #pragma nounroll
             for (uint32_t t0 = 0; t0 < CLUSTER; t0 += WALK_BATCH) {     // WALK_BATCH records in flight per lane
-                float4 rec[WALK_BATCH];
-#pragma unroll
-                for (int u = 0; u < WALK_BATCH; ++u) rec[u] = child[min(first + t0 + u, last)];
                 uint32_t keep_bits = 0;
+                if constexpr (MODE == 4) {
+                    float4 lo[WALK_BATCH], hi[WALK_BATCH];
 #pragma unroll
-                for (int u = 0; u < WALK_BATCH; ++u) {
-                    const bool keep = active && first + t0 + u <= last &&
-                                      ((MODE == 2 ? cone_keeps(dd, rec[u]) : (GROWN ? sphere_keeps_grown(dd, mm, al, rec[u], gr) : sphere_keeps(dd, mm, al, rec[u]))) || keep_all);
-                    keep_bits |= keep ? 1u << u : 0u;
+                    for (int u = 0; u < WALK_BATCH; ++u) {
+                        const size_t c = min(first + t0 + u, last);
+                        lo[u] = child[c * 2]; hi[u] = child[c * 2 + 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < WALK_BATCH; ++u) {
+                        const bool keep = active && first + t0 + u <= last && ((GROWN ? box_keeps_grown(ray, lo[u], hi[u], gr) : box_keeps(ray, lo[u], hi[u])) || keep_all);
+                        keep_bits |= keep ? 1u << u : 0u;
+                    }
+                } else {
+                    float4 rec[WALK_BATCH];
+#pragma unroll
+                    for (int u = 0; u < WALK_BATCH; ++u) rec[u] = child[min(first + t0 + u, last)];
+#pragma unroll
+                    for (int u = 0; u < WALK_BATCH; ++u) {
+                        const bool keep = active && first + t0 + u <= last &&
+                                          ((MODE == 2 ? cone_keeps(dd, rec[u]) : (GROWN ? sphere_keeps_grown(dd, mm, al, rec[u], gr) : sphere_keeps(dd, mm, al, rec[u]))) || keep_all);
+                        keep_bits |= keep ? 1u << u : 0u;
+                    }
                 }
 #pragma nounroll
                 for (uint32_t half = 0; half < WALK_BATCH / 4; ++half) {     // not unrolled: one copy of the code behind drain_out
@@ -1456,17 +1621,26 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
 
     wave_sync();
     for (uint32_t c0 = split.first_prim; c0 < split.end_prim; c0 += 64) {
-        const float4 mine = top_stream[min(c0 + lane, split.end_prim - 1u)];
-        const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine) : packet_sphere_keeps(packet, mine);
+        const size_t mine_at = min(c0 + lane, split.end_prim - 1u);
+        const float4 mine = top_stream[MODE == 4 ? mine_at * 2 : mine_at];
+        const float4 mine_hi = MODE == 4 ? top_stream[mine_at * 2 + 1] : mine;
+        const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine) : packet_sphere_keeps(packet, MODE == 4 ? box_sphere(mine, mine_hi) : mine);
         unsigned long long mask = __ballot((reach || keep_all) && c0 + lane < split.end_prim);
         while (mask) {
             const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mask));
             mask &= mask - 1ull;
             const float4 c = readlane4(mine, bit);
             uint32_t keep_bits = 0;
+            if constexpr (MODE == 4) {
+                const float4 c_hi = readlane4(mine_hi, bit);
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                keep_bits |= ((MODE == 2 ? cone_keeps(d[r], c) : (GROWN ? sphere_keeps_grown(d[r], moment[r], along[r], c, grow[r]) : sphere_keeps(d[r], moment[r], along[r], c))) || keep_all) && valid[r] ? 1u << r : 0u;
+                for (int r = 0; r < R; ++r)
+                    keep_bits |= ((GROWN ? box_keeps_grown(box_ray[r], c, c_hi, grow[r]) : box_keeps(box_ray[r], c, c_hi)) || keep_all) && valid[r] ? 1u << r : 0u;
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    keep_bits |= ((MODE == 2 ? cone_keeps(d[r], c) : (GROWN ? sphere_keeps_grown(d[r], moment[r], along[r], c, grow[r]) : sphere_keeps(d[r], moment[r], along[r], c))) || keep_all) && valid[r] ? 1u << r : 0u;
+            }
             if (__any(keep_bits != 0u)) {
                 if (q0_count + PUSH_MAX > QCAP) drain0();
                 push_bits(q0, q0_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
@@ -1480,7 +1654,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     if (lane == 0 && n_pairs) atomicAdd(stat_slot(st, ST_PAIR_PRETESTS), n_pairs);
     if (lane == 0 && n_queued) atomicAdd(stat_slot(st, ST_QUEUED), static_cast<unsigned long long>(n_queued));
     {   // FLOP executed in per-ray tests (n_full is per lane; the others are wave totals)
-        constexpr unsigned long long CHILD = MODE == 2 ? 6 : 18, LEAF = PRIM == 0 ? 40 : (PRIM == 1 ? 95 : 19), FULL = PRIM == 0 ? 54 : 0;
+        constexpr unsigned long long CHILD = MODE == 2 ? 6 : (MODE == 3 ? 18 : 24), LEAF = PRIM == 0 ? 40 : (PRIM == 1 ? 95 : 19), FULL = PRIM == 0 ? 54 : 0;
         block_add_stat(stat_slot(st, ST_FLOP), FULL * n_full + (lane == 0 ? CHILD * n_pairs + LEAF * n_queued : 0ull));
     }
 }
@@ -1759,6 +1933,10 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     bool valid[R], blocked[R];
     V3 d[R], moment[R];
     float along[R];
+    BoxRay box_ray[R];      // MODE 4
+    // the segment toward a point light ends at the light for triangles and spheres (their tests compare the distance itself);
+    // the ellipsoid test compares in its own space, so its boxes are tested against the whole half line
+    constexpr bool LIMITED = PRIM != 1;
     Packet packet;
     bool unsafe = false;
     {
@@ -1773,12 +1951,13 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             d[r] = s.d;
             moment[r] = scross(s.o, s.d);
             along[r] = sphere_along(s.o, s.d, sc.origin_bound);
+            if (MODE == 4) box_ray[r] = make_box_ray(s.o, s.d, LIMITED ? s.limit : FLT_MAX);
             unsafe |= !(fmaxf(fabsf(s.o.x), fmaxf(fabsf(s.o.y), fabsf(s.o.z))) <= sc.origin_bound);
             if (!point) unsafe |= !(vdot(s.d, s.d) <= SPH_DIR_CHECK);   // a directional light's direction is the caller's: the pre-tests need unit length
             blocked[r] = (st.blocked[slot[r]] & light_bit) != 0u;
             if (MODE != 0) lds_queue[(threadIdx.x >> 6) * WAVE_LDS + 3 * QCAP + r * 64 + (threadIdx.x & 63u)] = slot[r];
         }
-        if (MODE != 0) packet = uniform_packet(make_packet<R>(d, MODE == 3 ? o : nullptr, valid));
+        if (MODE != 0) packet = uniform_packet(make_packet<R>(d, MODE >= 3 ? o : nullptr, valid));
     }
     lds_blocked[threadIdx.x] = 0u;
     wave_sync();
@@ -1798,9 +1977,9 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     uint32_t q0_count = 0, q1_count = 0, q2_count = 0, n_full = 0, n_queued = 0;
     unsigned long long n_pairs = 0;
     const size_t light_index = MODE == 2 ? light - sc.has_directional : 0u;
-    const float4* __restrict__ top_stream = MODE == 2 ? h.top_light + light_index * h.n_tops : h.top_sphere;
-    const float4* __restrict__ cluster_stream = MODE == 2 ? h.cl_light + light_index * h.n_clusters : h.cl_sphere;
-    const float4* __restrict__ member_stream = MODE == 2 ? h.leaf_light + light_index * h.n : h.leaf_sphere;
+    const float4* __restrict__ top_stream = MODE == 2 ? h.top_light + light_index * h.n_tops : (MODE == 4 ? h.top_box : h.top_sphere);
+    const float4* __restrict__ cluster_stream = MODE == 2 ? h.cl_light + light_index * h.n_clusters : (MODE == 4 ? h.cl_box : h.cl_sphere);
+    const float4* __restrict__ member_stream = MODE == 2 ? h.leaf_light + light_index * h.n : (MODE == 4 ? h.leaf_box : h.leaf_sphere);
     // blocked bits of the wave's rays live in lds_blocked[thread that holds the ray], bit r; ray = r*64 + lane
     auto ray_blocked = [&](uint32_t ray) {
         return ((__hip_atomic_load(&lds_blocked[wave * 64u + (ray & 63u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> (ray >> 6)) & 1u) != 0u;
@@ -1856,18 +2035,33 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             const ShadowRay s = make_shadow_ray(st, wave_slots[e >> 24], point, lv);
             const V3 mm = scross(s.o, s.d);
             const float al = sphere_along(s.o, s.d, sc.origin_bound);
+            const BoxRay ray = make_box_ray(s.o, s.d, LIMITED ? s.limit : FLT_MAX);
             const uint32_t last = n_child - 1u;
             static_assert(CLUSTER % WALK_BATCH == 0 && WALK_BATCH % 4 == 0, "the walk takes WALK_BATCH children at a time, pushed four by four");
 #pragma nounroll
             for (uint32_t t0 = 0; t0 < CLUSTER; t0 += WALK_BATCH) {     // WALK_BATCH records in flight per lane
-                float4 rec[WALK_BATCH];
-#pragma unroll
-                for (int u = 0; u < WALK_BATCH; ++u) rec[u] = child[min(first + t0 + u, last)];
                 uint32_t keep_bits = 0;
+                if constexpr (MODE == 4) {
+                    float4 lo[WALK_BATCH], hi[WALK_BATCH];
 #pragma unroll
-                for (int u = 0; u < WALK_BATCH; ++u) {
-                    const bool keep = active && first + t0 + u <= last && ((MODE == 2 ? cone_keeps(s.d, rec[u]) : sphere_keeps(s.d, mm, al, rec[u])) || keep_all);
-                    keep_bits |= keep ? 1u << u : 0u;
+                    for (int u = 0; u < WALK_BATCH; ++u) {
+                        const size_t c = min(first + t0 + u, last);
+                        lo[u] = child[c * 2]; hi[u] = child[c * 2 + 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < WALK_BATCH; ++u) {
+                        const bool keep = active && first + t0 + u <= last && (box_keeps(ray, lo[u], hi[u]) || keep_all);
+                        keep_bits |= keep ? 1u << u : 0u;
+                    }
+                } else {
+                    float4 rec[WALK_BATCH];
+#pragma unroll
+                    for (int u = 0; u < WALK_BATCH; ++u) rec[u] = child[min(first + t0 + u, last)];
+#pragma unroll
+                    for (int u = 0; u < WALK_BATCH; ++u) {
+                        const bool keep = active && first + t0 + u <= last && ((MODE == 2 ? cone_keeps(s.d, rec[u]) : sphere_keeps(s.d, mm, al, rec[u])) || keep_all);
+                        keep_bits |= keep ? 1u << u : 0u;
+                    }
                 }
 #pragma nounroll
                 for (uint32_t half = 0; half < WALK_BATCH / 4; ++half) {     // not unrolled: one copy of the code behind drain_out
@@ -1923,17 +2117,25 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
         };
         uint32_t live = live_rays(), steps = 0;
         for (uint32_t c0 = split.first_prim; c0 < split.end_prim && live != 0; c0 += 64) {
-            const float4 mine = top_stream[min(c0 + lane, split.end_prim - 1u)];
+            const size_t mine_at = min(c0 + lane, split.end_prim - 1u);
+            const float4 mine = top_stream[MODE == 4 ? mine_at * 2 : mine_at];
+            const float4 mine_hi = MODE == 4 ? top_stream[mine_at * 2 + 1] : mine;
             wave_tests += static_cast<unsigned long long>(min(h.n, min(c0 + 64u, split.end_prim) * (CLUSTER * CLUSTER)) - c0 * (CLUSTER * CLUSTER)) * live;
-            const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine) : packet_sphere_keeps(packet, mine);
+            const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine) : packet_sphere_keeps(packet, MODE == 4 ? box_sphere(mine, mine_hi) : mine);
             unsigned long long mask = __ballot((reach || keep_all) && c0 + lane < split.end_prim);
             while (mask) {
                 const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mask));
                 mask &= mask - 1ull;
                 const float4 c = readlane4(mine, bit);
                 uint32_t keep_bits = 0;
+                if constexpr (MODE == 4) {
+                    const float4 c_hi = readlane4(mine_hi, bit);
 #pragma unroll
-                for (int r = 0; r < R; ++r) keep_bits |= ((MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], along[r], c)) || keep_all) && valid[r] && !blocked[r] ? 1u << r : 0u;
+                    for (int r = 0; r < R; ++r) keep_bits |= (box_keeps(box_ray[r], c, c_hi) || keep_all) && valid[r] && !blocked[r] ? 1u << r : 0u;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) keep_bits |= ((MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], along[r], c)) || keep_all) && valid[r] && !blocked[r] ? 1u << r : 0u;
+                }
                 if (__any(keep_bits != 0u)) {
                     if (q0_count + PUSH_MAX > QCAP) drain0();
                     push_bits(q0, q0_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
@@ -1951,7 +2153,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     if ((threadIdx.x & 63u) == 0 && n_pairs) atomicAdd(stat_slot(st, ST_PAIR_PRETESTS_SHADOW), n_pairs);
     if ((threadIdx.x & 63u) == 0 && n_queued) atomicAdd(stat_slot(st, ST_QUEUED_SHADOW), static_cast<unsigned long long>(n_queued));
     if (MODE != 0) {   // FLOP executed in per-ray tests (n_full is per lane; the others are wave totals)
-        constexpr unsigned long long CHILD = MODE == 2 ? 6 : 18, LEAF = PRIM == 0 ? 40 : (PRIM == 1 ? 71 : 19), FULL = PRIM == 0 ? 54 : 0;
+        constexpr unsigned long long CHILD = MODE == 2 ? 6 : (MODE == 3 ? 18 : 24), LEAF = PRIM == 0 ? 40 : (PRIM == 1 ? 71 : 19), FULL = PRIM == 0 ? 54 : 0;
         block_add_stat(stat_slot(st, ST_FLOP_SHADOW), FULL * n_full + ((threadIdx.x & 63u) == 0 ? CHILD * n_pairs + LEAF * n_queued : 0ull));
     }
 }
@@ -2212,6 +2414,7 @@ struct rt_scene {
     mutable EyeRecords eye_tri, eye_ell, eye_sph;
     mutable float eye[3] = {0, 0, 0};
     mutable bool eye_valid = false;
+    mutable float box_bound = 0.0f;    // bound of ray origins the box records were built for (0: not built yet)
     bool directional_is_unit = true;   // |direction|^2 <= 1 + 20 * 2^-24: the shadow scans toward it may use the pre-tests
 };
 
@@ -2282,15 +2485,53 @@ hipEvent_t sync_event(Lane& lane, size_t i) {
     return lane.sync_events[i];
 }
 
+// (Re)builds the box records of every kind for ray origins within `bound` (max norm) of 0.
+void build_boxes(const rt_scene* scene, float bound, hipStream_t stream) {
+    const DevScene& sc = scene->dev;
+    for (int prim = 0; prim < 3; ++prim) {
+        const Hierarchy& h = prim == 0 ? sc.th : (prim == 1 ? sc.eh : sc.sh);
+        if (h.n == 0) continue;
+        float4* leaf = const_cast<float4*>(h.leaf_box);
+        float4* cl = const_cast<float4*>(h.cl_box);
+        float4* top = const_cast<float4*>(h.top_box);
+        const dim3 leaf_grid(ceil_div(h.n, BLOCK)), cl_grid(ceil_div(h.n_clusters, BLOCK)), top_grid(ceil_div(h.n_tops, BLOCK));
+        if (prim == 0) hipLaunchKernelGGL(k_prep_tri_box, leaf_grid, dim3(BLOCK), 0, stream, sc.tri, h.k_of, h.n, bound, leaf);
+        else if (prim == 1) hipLaunchKernelGGL(k_prep_ell_box, leaf_grid, dim3(BLOCK), 0, stream, sc.ell, h.k_of, h.n, bound, leaf);
+        else hipLaunchKernelGGL(k_prep_sph_box, leaf_grid, dim3(BLOCK), 0, stream, sc.sph, h.k_of, h.n, bound, leaf);
+        hipLaunchKernelGGL(k_prep_cluster_box, cl_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(leaf), h.n, h.n_clusters, cl);
+        hipLaunchKernelGGL(k_prep_cluster_box, top_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(cl), h.n_clusters, h.n_tops, top);
+    }
+    scene->box_bound = bound;
+}
+// Which ray classes walk the box records instead of the cone / sphere records: bit 0 rays from the eye,
+// 1 reflected rays, 2 shadow rays toward point lights, 3 toward the directional light.
+// RT_AMD_BOX in the environment overrides the default (tuning).
+constexpr uint32_t BOX_DEFAULT = 15;
+uint32_t box_classes() {
+    static const uint32_t value = [] {
+        const char* e = std::getenv("RT_AMD_BOX");
+        return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : BOX_DEFAULT;
+    }();
+    return value;
+}
+
 const Hierarchy& hierarchy_of(const DevScene& sc, int prim) { return prim == 0 ? sc.th : (prim == 1 ? sc.eh : sc.sh); }
 // hierarchy scans of one kind: rays per lane (1 or 2) and record kind (cone records for rays through a common point, else sphere records)
 template <int PRIM>
 void launch_closest_scan(bool two, bool eye_rays, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b) {
+    if (box_classes() & (eye_rays ? 1u : 2u)) {
+        if (two) hipLaunchKernelGGL((k_closest_scan<2, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b); else hipLaunchKernelGGL((k_closest_scan<1, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b);
+        return;
+    }
     if (eye_rays) { if (two) hipLaunchKernelGGL((k_closest_scan<2, 2, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b); else hipLaunchKernelGGL((k_closest_scan<1, 2, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b); }
     else { if (two) hipLaunchKernelGGL((k_closest_scan<2, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b); else hipLaunchKernelGGL((k_closest_scan<1, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b); }
 }
 template <int PRIM>
 void launch_shadow_scan(bool two, bool point_lights, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b, uint32_t first_light, uint32_t group_first) {
+    if (box_classes() & (point_lights ? 4u : 8u)) {
+        if (two) hipLaunchKernelGGL((k_shadow_scan<2, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first);
+        return;
+    }
     if (point_lights) { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 2, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 2, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first); }
     else { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first); }
 }
@@ -2341,6 +2582,16 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         HIP_TRY(hipGetLastError());
         std::memcpy(scene->eye, cam->eye, sizeof scene->eye);
         scene->eye_valid = true;
+    }
+    {   // the box records must hold for the eye as an origin too
+        float need = sc.origin_bound;
+        for (int i = 0; i < 3; ++i) need = std::fmax(need, 1.001f * std::fabs(cam->eye[i]) + 1.0e-3f);
+        if (!(need <= scene->box_bound)) {
+            if (!std::isfinite(need)) return rt_fail(RT_ERR_ARGUMENT, "camera eye is not finite");
+            build_boxes(scene, need, stream);
+            HIP_TRY(hipGetLastError());
+        }
+        sc.box_bound = scene->box_bound;
     }
     sc.th.leaf_eye = scene->eye_tri.leaf; sc.th.cl_eye = scene->eye_tri.cl; sc.th.top_eye = scene->eye_tri.top;
     sc.eh.leaf_eye = scene->eye_ell.leaf; sc.eh.cl_eye = scene->eye_ell.cl; sc.eh.top_eye = scene->eye_ell.top;
@@ -2761,6 +3012,11 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
         if ((rc = upload<float4>(s, nullptr, h.n, &leaf_sphere))) return fail(rc);
         if ((rc = upload<float4>(s, nullptr, h.n_clusters, &cl_sphere))) return fail(rc);
         if ((rc = upload<float4>(s, nullptr, h.n_tops, &top_sphere))) return fail(rc);
+        float4 *leaf_box, *cl_box, *top_box;
+        if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n) * 2, &leaf_box))) return fail(rc);
+        if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n_clusters) * 2, &cl_box))) return fail(rc);
+        if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n_tops) * 2, &top_box))) return fail(rc);
+        h.leaf_box = leaf_box; h.cl_box = cl_box; h.top_box = top_box;
         h.k_of = k_of;
         h.leaf_light = leaf_light; h.cl_light = cl_light; h.top_light = top_light;
         h.leaf_sphere = leaf_sphere; h.cl_sphere = cl_sphere; h.top_sphere = top_sphere;
@@ -2808,6 +3064,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     std::memcpy(d.ambient, desc->ambient, sizeof d.ambient);
     std::memcpy(d.atten, desc->attenuation, sizeof d.atten);
 
+    build_boxes(s, d.origin_bound, stream);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return fail(rt_fail(RT_ERR_DEVICE, "rt_scene_create: scene preparation kernels failed"));
     *out = s;
     return 0;
