@@ -16,8 +16,8 @@
 // Two ways through the primitive lists give the same bytes:
 //   brute force (RT_FLAG_NO_FILTER): every ray against every primitive through the literal
 //     test of the reference, records staged in LDS tiles and read as broadcasts;
-//   default: conservative bounds (cones, spheres) over a three-level hierarchy of the
-//     primitives decide almost every pair; what is left goes through the same literal test.
+//   default: conservative bounds (axis-aligned boxes, slab test) over a three-level hierarchy
+//     of the primitives decide almost every pair; what is left goes through the same literal test.
 //     The closest hit is an atomicMin over (distance, scan index) keys, so the order of
 //     the visits does not matter.
 //
@@ -71,7 +71,7 @@ constexpr int TILE_PRIMS = 256;           // primitives staged in LDS per step (
 #ifndef RT_CLUSTER
 #define RT_CLUSTER 16
 #endif
-constexpr uint32_t CLUSTER = RT_CLUSTER;          // triangles per cluster of the pre-test records
+constexpr uint32_t CLUSTER = RT_CLUSTER;          // children per node of the box hierarchy
 constexpr uint32_t SAMPLES_PER_TILE = RT_TILE * RT_TILE * RT_SAMPLES_PER_PIXEL;  // 4096
 
 // Primitive lists are stored in "scan order": entry k holds the primitive the reference
@@ -81,20 +81,16 @@ constexpr uint32_t SAMPLES_PER_TILE = RT_TILE * RT_TILE * RT_SAMPLES_PER_PIXEL; 
 // by walking k upward with a strict `<` and the hierarchy scans by an atomicMin over
 // (distance, k) keys (pack_hit).
 
-// Bounding records of one primitive kind (triangles, ellipsoids or spheres), 1 x float4 each, for the
-// conservative pre-tests of the scans.  Three kinds of record: "eye" = cone of directions from the
-// camera eye (cone_keeps), "light" = the same from each point light, "sphere" = bounding sphere for
-// rays with their own origin (sphere_keeps).  Three levels: leaves (one per primitive), clusters
-// (CLUSTER consecutive leaves) and top nodes (CLUSTER consecutive clusters); a cluster or top record
-// contains the records of everything below it.  Leaves are stored in CLUSTER ORDER: position s
-// holds the primitive with scan index k_of[s], and consecutive positions are neighbours in space
-// (leaf order of a kd tree, built by the host at scene creation).
+// Bounding records of one primitive kind (triangles, ellipsoids or spheres) for the conservative
+// pre-test of the scans: axis-aligned boxes, 2 x float4 per node, (lo, 0) (hi, 0), see box_keeps.
+// Three levels: leaves (one per primitive), clusters (CLUSTER consecutive leaves) and top nodes
+// (CLUSTER consecutive clusters); the box of a cluster or top node contains the boxes of everything
+// below it.  Leaves are stored in CLUSTER ORDER: position s holds the primitive with scan index
+// k_of[s], and consecutive positions are neighbours in space (leaf order of a kd tree, built by
+// the host at scene creation).  One hierarchy serves every ray: from the eye, reflected, shadow.
 struct Hierarchy {
     const uint32_t* k_of;
-    const float4 *leaf_eye, *leaf_light, *leaf_sphere;   // leaf_light: [point light][position]
-    const float4 *cl_eye, *cl_light, *cl_sphere;
-    const float4 *top_eye, *top_light, *top_sphere;
-    const float4 *leaf_box, *cl_box, *top_box;            // 2 x float4 per node: (lo, 0) (hi, 0), see box_keeps
+    const float4 *leaf_box, *cl_box, *top_box;
     uint32_t n, n_clusters, n_tops;
 };
 
@@ -324,48 +320,6 @@ DEV bool pretest_stage2(const Pre& s, float4 f3) {
     return !(u < 0.5f - s.thr);
 }
 
-// Cone pre-test for rays that pass through one common point X: camera rays (X = eye) and
-// shadow rays toward a point light (X = light position).  Seen from X, a triangle (inflated by
-// the margin m of the two-stage pre-test, and for shadow rays by the rounding of the direction
-// (X - origin)/|X - origin| that the full test uses) lies inside a cone of directions around an
-// axis; a unit direction d outside that cone cannot hit it.  One dot product and one compare
-// per ray and triangle.  The record (k_prep_cone, in double) is (axis, cos(half angle)) with the
-// cosine lowered by the rounding of d.axis; cos = -2 keeps every ray.  NaN keeps the ray.
-DEV bool cone_keeps(V3 d, float4 c) { return !(vdot(d, xyz(c)) < c.w); }
-
-// Sphere pre-test for a ray with its own origin o, in its Pluecker coordinates (d, m = o x d)
-// with d of unit length: the distance of a point c from the ray's line is |c x d - m|.  If that
-// exceeds the radius of a sphere around c that contains every hit point the full test can accept
-// on the primitive, the ray cannot hit.  Six multiply-adds for c x d - m, three for the squared
-// length, one compare; the record (k_prep_sphere, in double) is (c, r^2) with r enlarged by the
-// rounding of m, of this expression and of the normalised direction.
-// Hits lie ahead of the origin, so the sphere must not lie wholly behind it either:
-// (c - o).d >= -r.  `along` is o.d lowered by SPHERE_BEHIND_SLACK * origin bound, which is more
-// than twice the rounding of u = c.d - along (both dot products, |c|_inf and |o|_inf within the
-// origin bound, d off unit length by 2^-23); the sphere is behind when u < 0 and u^2 > r^2.
-// r^2 = inf keeps every ray; NaN keeps the ray.
-constexpr float SPHERE_BEHIND_SLACK = 64.0f * 5.9604644775390625e-8f;
-DEV bool sphere_keeps(V3 d, V3 m, float along, float4 c) {
-    const float vx = fma_(c.y, d.z, fma_(-c.z, d.y, -m.x));
-    const float vy = fma_(c.z, d.x, fma_(-c.x, d.z, -m.y));
-    const float vz = fma_(c.x, d.y, fma_(-c.y, d.x, -m.z));
-    const float q = fma_(vz, vz, fma_(vy, vy, vx * vx));
-    const float u = vdot(xyz(c), d) - along;
-    return !(q > c.w) && !(u < 0.0f && u * u > c.w);
-}
-// The same with the radius enlarged by `grow` (>= 0): (sqrt(r^2) + grow)^2 = r^2 + grow (grow + 2 sqrt(r^2)); the
-// approximate square root (1 ulp) is covered by the factor 2.0002.  grow = 0 gives sphere_keeps exactly.
-DEV bool sphere_keeps_grown(V3 d, V3 m, float along, float4 c, float grow) {
-    const float vx = fma_(c.y, d.z, fma_(-c.z, d.y, -m.x));
-    const float vy = fma_(c.z, d.x, fma_(-c.x, d.z, -m.y));
-    const float vz = fma_(c.x, d.y, fma_(-c.y, d.x, -m.z));
-    const float q = fma_(vz, vz, fma_(vy, vy, vx * vx));
-    const float u = vdot(xyz(c), d) - along;
-    const float rr = fma_(grow, fma_(2.0002f, __builtin_amdgcn_sqrtf(c.w), grow), c.w);
-    return !(q > rr) && !(u < 0.0f && u * u > rr);
-}
-DEV float sphere_along(V3 o, V3 d, float origin_bound) { return vdot(o, d) - SPHERE_BEHIND_SLACK * origin_bound; }
-
 // Box pre-test (slab test) for any ray: the record is an axis-aligned box that contains every hit
 // point the full tests can accept on the primitives below the node; a ray whose segment
 // [0, limit] misses the box cannot hit them.  inv = 1/d per component (approximate reciprocal,
@@ -393,7 +347,7 @@ DEV bool box_keeps_grown(const BoxRay& r, float4 lo, float4 hi, float grow) {
     hi.x += grow; hi.y += grow; hi.z += grow;
     return box_keeps(r, lo, hi);
 }
-// Bounding sphere (centre, radius^2) of a box record, for the per-wave test (packet_sphere_keeps)
+// Sphere (centre, radius^2) around a box record, for the per-wave test (packet_sphere_keeps)
 DEV float4 box_sphere(float4 lo, float4 hi) {
     const V3 c{0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
     const V3 h{hi.x - c.x, hi.y - c.y, hi.z - c.z};
@@ -402,24 +356,17 @@ DEV float4 box_sphere(float4 lo, float4 hi) {
     return make_float4(c.x, c.y, c.z, vdot(e, e) * 1.00001f);
 }
 
-// Per-wave ("packet") pre-test, ahead of cone_keeps / sphere_keeps.  A wave's rays are neighbours
-// in the image, so they fit in a narrow bound: a cone of directions (unit axis A, cosine cw of the
-// half angle) and, for rays with their own origins, a ball (O, rho) around the origins.  One lane
-// tests one triangle record against the bound of the whole wave, so a triangle the wave cannot
-// reach costs 1/64 of a lane-instruction sequence instead of one per ray.
-//
-// Cone records (rays through a common point X): a ray of the wave hits the triangle only if its
-// direction lies in both cones, hence only if angle(A, axis) <= theta_w + theta_t, i.e.
-// A.axis >= cw*ct - sw*st.  1 - c*c is evaluated with one fused multiply-add, so the sines carry
-// a relative error of about 2^-23 even for cosines next to 1.  All roundings together (the two dot
-// products, |A| and |axis| off 1 by a few 2^-24, the products) stay below 1e-6 in the comparison;
-// cw is lowered by 1e-6 when it is formed and the threshold by another 2e-6.
-// Sphere records (c, r^2): moving every origin to O enlarges the sphere to r + rho; seen from O it
-// spans the half angle psi = asin((r + rho)/|c - O|), and the wave reaches it only if
-// angle(A, c - O) <= theta_w + psi.  sin(psi) is inflated by 2e-5 relative, which covers the
-// approximate sqrt/rsq (1 ulp each) and the rounding of its cosine.
-// Both tests need theta_w < 90 degrees (cw > 0), so that the angle sums stay below 180; a wider
-// wave, NaN or infinity anywhere keeps the triangle.
+// Per-wave ("packet") pre-test, ahead of box_keeps.  A wave's rays are neighbours in the image, so
+// they fit in a narrow bound: a cone of directions (unit axis A, cosine cw of the half angle) and a
+// ball (O, rho) around the origins.  One lane tests one top node against the bound of the whole
+// wave, so a node the wave cannot reach costs 1/64 of a lane-instruction sequence instead of one
+// per ray.  The node's box is replaced by the sphere around it (box_sphere: centre c, radius r).
+// Moving every origin to O enlarges the sphere to r + rho; seen from O it spans the half angle
+// psi = asin((r + rho)/|c - O|), and the wave reaches it only if angle(A, c - O) <= theta_w + psi.
+// sin(psi) is inflated by 2e-5 relative, which covers the approximate sqrt/rsq (1 ulp each) and the
+// rounding of its cosine; cw is lowered by 1e-6 when it is formed and the threshold by another 2e-6
+// (the dot products, |A| off 1 by a few 2^-24, the products).  The test needs theta_w < 90 degrees
+// (cw > 0), so that the angle sum stays below 180; a wider wave, NaN or infinity anywhere keeps the node.
 struct Packet { V3 A; float cw, sw; V3 O; float rho, o1; };
 DEV float wave_sum(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -486,13 +433,6 @@ DEV Packet uniform_packet(Packet p) {
     p.O = {uni(p.O.x), uni(p.O.y), uni(p.O.z)};
     p.rho = uni(p.rho); p.o1 = uni(p.o1);
     return p;
-}
-DEV bool packet_cone_keeps(const Packet& p, float4 c) {
-    // along >= cw*ct - sw*st, with x = along - cw*ct (+ slack):  x >= 0, or x^2 <= sw^2 st^2 = sw^2 (1 - ct^2)
-    const float along = vdot(p.A, xyz(c));
-    const float x = fma_(-p.cw, c.w, along) + 2.0e-6f;
-    const float rhs = (p.sw * p.sw) * (fma_(-c.w, c.w, 1.0f) * 1.00001f);
-    return !(x < 0.0f) || !(x * x > rhs) || !(c.w > 0.0f) || !(p.cw > 0.0f);
 }
 DEV bool packet_sphere_keeps(const Packet& p, float4 c) {
     const V3 v = sub(xyz(c), p.O);
@@ -632,193 +572,6 @@ __global__ void __launch_bounds__(BLOCK) k_reorder_pretest_records(const float4*
     o[3] = f[3];
 }
 
-// Cone records (cone_keeps) for rays through X.  `reversed` = 0: X is the camera eye, the full
-// test starts at X with the unit direction d that is also tested here.  `reversed` = 1: X is a
-// point light; the full test starts at an origin within origin_bound of 0 with the rounded unit
-// direction d toward X, and the axis stored is the one d itself has to be close to.
-// All in double.  Let m bound the barycentric error of the full test (as in the two-stage
-// pre-test, with |t| bounded by the distance to the farthest point of the triangle): whenever
-// the full test accepts, its hit point lies within delta of the triangle scaled by (1 + 3m)
-// about its centroid, where delta covers the hit point being slightly off the plane and, for
-// shadow rays, the rounding of the direction.  The cone is the one around the direction to the
-// centroid that contains the three scaled vertices, widened by asin(delta / distance).
-__global__ void __launch_bounds__(BLOCK) k_prep_cone(const float4* __restrict__ tri, const uint32_t* __restrict__ k_of, uint32_t n_tri, float x, float y, float z,
-                                                     float origin_bound, int reversed, float4* __restrict__ out) {
-    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
-    if (pos >= n_tri) return;
-    const uint32_t k = k_of[pos];
-    const float4 t0 = tri[static_cast<size_t>(k) * 4], t1 = tri[static_cast<size_t>(k) * 4 + 1], t2 = tri[static_cast<size_t>(k) * 4 + 2], t3 = tri[static_cast<size_t>(k) * 4 + 3];
-    const double a[3] = {t0.x, t0.y, t0.z}, n[3] = {t0.w, t1.w, t2.w}, ab[3] = {t1.x, t1.y, t1.z}, ac[3] = {t2.x, t2.y, t2.z};
-    const double X[3] = {x, y, z};
-    const double nn = static_cast<double>(t3.x);
-    auto max3 = [](const double* v) { return fmax(fabs(v[0]), fmax(fabs(v[1]), fabs(v[2]))); };
-    auto len3 = [](const double* v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
-    float4 rec = make_float4(0.0f, 0.0f, 0.0f, -2.0f);   // keeps every ray
-    const double eps = 5.9604644775390625e-8;   // 2^-24
-    const double n_one = fabs(n[0]) + fabs(n[1]) + fabs(n[2]);
-    const double edges = len3(ab) + len3(ac);
-    double ax[3], c[3], v[3][3];
-    for (int i = 0; i < 3; ++i) {
-        ax[i] = a[i] - X[i];
-        c[i] = a[i] + (ab[i] + ac[i]) / 3.0;
-        v[0][i] = a[i]; v[1][i] = a[i] + ab[i]; v[2][i] = a[i] + ac[i];
-    }
-    if (nn > 0.0) {
-        const double Q = max3(n) * fmax(max3(ab), max3(ac)) / nn;
-        double m, delta;
-        bool usable = true;
-        if (reversed) {
-            const double B = origin_bound;
-            const double T_p = 2.0 * (1.7320508075688772 * (max3(a) + B) + edges);   // origin of the full test to the hit
-            const double tol_eff = 1.0e-4 - 8.0 * eps * n_one;
-            usable = tol_eff > 2.0e-5;
-            m = 2.0 * (48.0 * eps * Q * (B + T_p + max3(a)) + eps);
-            delta = 2.0 * (13.0 * eps * T_p + 4.0 * eps * T_p);
-        } else {
-            const double T_x = 2.0 * (len3(ax) + edges);
-            m = 2.0 * (48.0 * eps * Q * (max3(X) + T_x + max3(a)) + eps);
-            delta = 2.0 * 13.0 * eps * T_x;
-        }
-        double axis[3], to_c[3];
-        for (int i = 0; i < 3; ++i) to_c[i] = c[i] - X[i];
-        const double dist_c = len3(to_c);
-        double cos_min = 1.0, r_b = 0.0;
-        bool ok = usable && dist_c > 0.0 && m < 1.0e6;
-        for (int i = 0; i < 3 && ok; ++i) axis[i] = to_c[i] / dist_c;
-        for (int j = 0; j < 3 && ok; ++j) {
-            double w[3], out_c[3];
-            for (int i = 0; i < 3; ++i) { out_c[i] = (1.0 + 3.0 * m) * (v[j][i] - c[i]); w[i] = c[i] + out_c[i] - X[i]; }
-            const double lw = len3(w);
-            r_b = fmax(r_b, len3(out_c));
-            if (!(lw > 0.0)) { ok = false; break; }
-            cos_min = fmin(cos_min, (w[0] * axis[0] + w[1] * axis[1] + w[2] * axis[2]) / lw);
-        }
-        const double d_min = dist_c - r_b - delta;
-        if (ok && d_min > 4.0 * delta && cos_min > -1.0) {
-            const double theta = acos(fmin(1.0, cos_min)) + asin(delta / d_min);
-            if (theta < 1.5) {
-                const double cos_store = cos(theta) * (1.0 - 8.0 * eps) - 16.0 * eps;
-                const double sign = reversed ? -1.0 : 1.0;
-                rec = make_float4(static_cast<float>(sign * axis[0]), static_cast<float>(sign * axis[1]), static_cast<float>(sign * axis[2]),
-                                  nextafterf(static_cast<float>(cos_store), -2.0f));
-                if (!(rec.w > -1.0f && rec.w < 1.0f)) rec = make_float4(0.0f, 0.0f, 0.0f, -2.0f);
-            }
-        }
-    }
-    out[pos] = rec;
-}
-
-// Bounding-sphere records (sphere_keeps) for rays whose origins lie within origin_bound of 0.
-// As in k_prep_cone: when the full test accepts, its hit point lies within delta of the triangle
-// scaled by (1 + 3m) about its centroid c.
-__global__ void __launch_bounds__(BLOCK) k_prep_sphere(const float4* __restrict__ tri, const uint32_t* __restrict__ k_of, uint32_t n_tri, float origin_bound, float4* __restrict__ out) {
-    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
-    if (pos >= n_tri) return;
-    const uint32_t k = k_of[pos];
-    const float4 t0 = tri[static_cast<size_t>(k) * 4], t1 = tri[static_cast<size_t>(k) * 4 + 1], t2 = tri[static_cast<size_t>(k) * 4 + 2], t3 = tri[static_cast<size_t>(k) * 4 + 3];
-    const double a[3] = {t0.x, t0.y, t0.z}, n[3] = {t0.w, t1.w, t2.w}, ab[3] = {t1.x, t1.y, t1.z}, ac[3] = {t2.x, t2.y, t2.z};
-    const double nn = static_cast<double>(t3.x);
-    auto max3 = [](const double* v) { return fmax(fabs(v[0]), fmax(fabs(v[1]), fabs(v[2]))); };
-    auto len3 = [](const double* v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
-    float4 rec = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());   // keeps every ray
-    if (nn > 0.0) {
-        const double eps = 5.9604644775390625e-8;   // 2^-24
-        const double B = origin_bound;
-        const double Q = max3(n) * fmax(max3(ab), max3(ac)) / nn;
-        const double edges = len3(ab) + len3(ac);
-        const double T = 2.0 * (1.7320508075688772 * (max3(a) + B) + edges);   // origin to any accepted hit, with slack
-        const double m = 2.0 * (48.0 * eps * Q * (B + T + max3(a)) + eps);
-        double c[3], r = 0.0;
-        for (int i = 0; i < 3; ++i) c[i] = a[i] + (ab[i] + ac[i]) / 3.0;
-        const double v[3][3] = {{a[0], a[1], a[2]}, {a[0] + ab[0], a[1] + ab[1], a[2] + ab[2]}, {a[0] + ac[0], a[1] + ac[1], a[2] + ac[2]}};
-        for (int j = 0; j < 3; ++j) {
-            const double e[3] = {v[j][0] - c[0], v[j][1] - c[1], v[j][2] - c[2]};
-            r = fmax(r, len3(e));
-        }
-        r *= 1.0 + 3.0 * m;
-        // hit point off the plane, direction normalised in binary32, centre rounded to binary32; then the
-        // rounding of m = o x d and of c x d - m
-        const double r_tot = (r + 2.0 * (13.0 * eps * T + 3.0 * eps * T + 2.0 * eps * max3(c))) * (1.0 + 6.0 * eps)
-                             + 2.0 * 13.0 * eps * (max3(c) + B);
-        const double r2 = r_tot * r_tot * (1.0 + 1.0e-6);
-        if (r2 < 1.0e30 && m < 1.0e6 && max3(c) <= B)   // sphere_keeps relies on |c|_inf <= origin bound
-            rec = make_float4(static_cast<float>(c[0]), static_cast<float>(c[1]), static_cast<float>(c[2]), nextafterf(static_cast<float>(r2), __builtin_inff()));
-    }
-    out[pos] = rec;
-}
-
-// Cluster records: one thread per cluster, in double.
-// Cone: axis = normalised sum of the members' axes, half angle = max over members of (angle between
-// the axes + the member's half angle); a member that keeps every ray makes the cluster keep every
-// ray.  The cosine is lowered as in k_prep_cone for the rounding of the dot product in the kernel.
-// A direction inside a member's cone (as the kernel evaluates it) is then inside the cluster's.
-__global__ void __launch_bounds__(BLOCK) k_prep_cluster_cone(const float4* __restrict__ member, uint32_t n_tri, uint32_t n_clusters, float4* __restrict__ out) {
-    const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
-    if (c >= n_clusters) return;
-    const uint32_t first = c * CLUSTER, count = min(CLUSTER, n_tri - first);
-    const double eps = 5.9604644775390625e-8;   // 2^-24
-    double sum[3] = {0.0, 0.0, 0.0};
-    bool all = false;
-    for (uint32_t t = 0; t < count; ++t) {
-        const float4 m = member[first + t];
-        if (!(m.w > -1.0f)) all = true;
-        sum[0] += m.x; sum[1] += m.y; sum[2] += m.z;
-    }
-    const double len = sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
-    float4 rec = make_float4(0.0f, 0.0f, 0.0f, -2.0f);   // keeps every ray
-    if (!all && len > 1.0e-3) {
-        const double axis[3] = {sum[0] / len, sum[1] / len, sum[2] / len};
-        double theta = 0.0;
-        for (uint32_t t = 0; t < count; ++t) {
-            const float4 m = member[first + t];
-            const double ml = sqrt(static_cast<double>(m.x) * m.x + static_cast<double>(m.y) * m.y + static_cast<double>(m.z) * m.z);
-            const double cosine = (axis[0] * m.x + axis[1] * m.y + axis[2] * m.z) / ml;
-            // the member's own cosine was lowered for its own evaluation; 16 eps more covers the member's axis being a rounded vector
-            theta = fmax(theta, acos(fmax(-1.0, fmin(1.0, cosine))) + acos(fmax(-1.0, fmin(1.0, static_cast<double>(m.w) - 16.0 * eps))));
-        }
-        theta += 1.0e-6;
-        if (theta < 1.5) {
-            const double cos_store = cos(theta) * (1.0 - 8.0 * eps) - 16.0 * eps;
-            rec = make_float4(static_cast<float>(axis[0]), static_cast<float>(axis[1]), static_cast<float>(axis[2]), nextafterf(static_cast<float>(cos_store), -2.0f));
-            if (!(rec.w > -1.0f && rec.w < 1.0f)) rec = make_float4(0.0f, 0.0f, 0.0f, -2.0f);
-        }
-    }
-    out[c] = rec;
-}
-// Sphere: centre = mean of the members' centres, radius = max over members of (distance of the
-// centres + the member's radius), then the same enlargements as in k_prep_sphere for the rounding of
-// the Pluecker expression with this centre.  A line within a member's radius of the member's centre
-// (as the kernel evaluates it) is then within the cluster's radius of the cluster's centre.
-__global__ void __launch_bounds__(BLOCK) k_prep_cluster_sphere(const float4* __restrict__ member, uint32_t n_tri, uint32_t n_clusters, float origin_bound, float4* __restrict__ out) {
-    const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
-    if (c >= n_clusters) return;
-    const uint32_t first = c * CLUSTER, count = min(CLUSTER, n_tri - first);
-    const double eps = 5.9604644775390625e-8;   // 2^-24
-    double sum[3] = {0.0, 0.0, 0.0};
-    bool all = false;
-    for (uint32_t t = 0; t < count; ++t) {
-        const float4 m = member[first + t];
-        if (!(m.w < 1.0e30f)) all = true;
-        sum[0] += m.x; sum[1] += m.y; sum[2] += m.z;
-    }
-    float4 rec = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());   // keeps every ray
-    if (!all) {
-        const float cf[3] = {static_cast<float>(sum[0] / count), static_cast<float>(sum[1] / count), static_cast<float>(sum[2] / count)};
-        const double centre[3] = {cf[0], cf[1], cf[2]};   // the binary32 centre the kernel will use
-        double r = 0.0;
-        for (uint32_t t = 0; t < count; ++t) {
-            const float4 m = member[first + t];
-            const double e[3] = {m.x - centre[0], m.y - centre[1], m.z - centre[2]};
-            r = fmax(r, sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + sqrt(static_cast<double>(m.w)));
-        }
-        const double c_max = fmax(fabs(centre[0]), fmax(fabs(centre[1]), fabs(centre[2])));
-        const double r_tot = r * (1.0 + 1.0e-6) * (1.0 + 6.0 * eps) + 2.0 * 13.0 * eps * (c_max + origin_bound);
-        const double r2 = r_tot * r_tot * (1.0 + 1.0e-6);
-        if (r2 < 1.0e30 && c_max <= origin_bound) rec = make_float4(cf[0], cf[1], cf[2], nextafterf(static_cast<float>(r2), __builtin_inff()));
-    }
-    out[c] = rec;
-}
-
 __global__ void __launch_bounds__(BLOCK) k_prep_spheres(const float* __restrict__ sph8, uint32_t nb, float4* __restrict__ out) {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= 8u * nb) return;
@@ -840,9 +593,9 @@ __global__ void __launch_bounds__(BLOCK) k_prep_ellipsoids(const float* __restri
     }
 }
 
-// Box records (box_keeps).  Leaves: the box of everything the full test can accept on the primitive
-// (the same regions as for the sphere records), rounded outward to binary32; clusters and top
-// nodes: the union of their children, which is exact.
+// Box records (box_keeps), built in double.  Leaves: a box that contains every hit point o + t d the
+// full test of the kind can accept on the primitive, for origins within origin_bound (max norm) of
+// 0, rounded outward to binary32; clusters and top nodes: the union of their children, which is exact.
 DEV void store_box(float4* __restrict__ out, uint32_t pos, const double* lo, const double* hi, bool ok) {
     const float inf = __builtin_inff();
     float4 l = make_float4(-inf, -inf, -inf, 0.0f), h = make_float4(inf, inf, inf, 0.0f);   // keeps every ray
@@ -853,7 +606,10 @@ DEV void store_box(float4* __restrict__ out, uint32_t pos, const double* lo, con
     out[static_cast<size_t>(pos) * 2] = l;
     out[static_cast<size_t>(pos) * 2 + 1] = h;
 }
-// triangles: as in k_prep_sphere, the hit point lies within delta of the triangle scaled by (1 + 3m) about its centroid
+// Triangles.  Let m bound the barycentric error of the full test (as in the two-stage pre-test,
+// with |t| bounded by T, the distance from an origin to the farthest point of the triangle, with
+// slack): whenever the full test accepts, its hit point lies within delta of the triangle scaled
+// by (1 + 3m) about its centroid, where delta = 26 eps T covers the hit point being off the plane.
 __global__ void __launch_bounds__(BLOCK) k_prep_tri_box(const float4* __restrict__ tri, const uint32_t* __restrict__ k_of, uint32_t n_tri, float origin_bound, float4* __restrict__ out) {
     const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
     if (pos >= n_tri) return;
@@ -963,65 +719,6 @@ __device__ double ell_reach(const EllBound& b, double D, double o_max) {
     if (!(rho < 8.0)) return INFINITY;
     return b.r_geom * rho * (1.0 + 1.0e-6);
 }
-// sphere records (sphere_keeps) of the ellipsoids, in cluster order
-__global__ void __launch_bounds__(BLOCK) k_prep_ell_sphere(const float4* __restrict__ ell, const uint32_t* __restrict__ k_of, uint32_t n, float origin_bound, float4* __restrict__ out) {
-    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
-    if (pos >= n) return;
-    const uint32_t k = k_of[pos];
-    const EllBound b = ell_bound(ell[static_cast<size_t>(k) * 6], ell[static_cast<size_t>(k) * 6 + 1], ell[static_cast<size_t>(k) * 6 + 2]);
-    float4 rec = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());   // keeps every ray
-    if (b.ok) {
-        const double eps = 5.9604644775390625e-8;
-        const double B = origin_bound;
-        const double c_len = sqrt(b.c[0] * b.c[0] + b.c[1] * b.c[1] + b.c[2] * b.c[2]);
-        const double c_max = fmax(fabs(b.c[0]), fmax(fabs(b.c[1]), fabs(b.c[2])));
-        const double D = 1.7320508075688772 * B + c_len;
-        const double r = ell_reach(b, D, B);
-        // as in k_prep_sphere: the pre-test's re-normalised direction, the centre rounded to binary32, m = o x d and c x d - m
-        const double T = 2.0 * (D + r);
-        const double r_tot = (r + 2.0 * (3.0 * eps * T + 2.0 * eps * c_max)) * (1.0 + 6.0 * eps) + 2.0 * 13.0 * eps * (c_max + B);
-        const double r2 = r_tot * r_tot * (1.0 + 1.0e-6);
-        if (r2 < 1.0e30 && c_max <= B) rec = make_float4(static_cast<float>(b.c[0]), static_cast<float>(b.c[1]), static_cast<float>(b.c[2]), nextafterf(static_cast<float>(r2), __builtin_inff()));
-    }
-    out[pos] = rec;
-}
-// cone records (cone_keeps) of the ellipsoids for rays through X, as k_prep_cone does for triangles:
-// reversed = 0: X is the eye and every ray starts there; reversed = 1: X is a point light, the
-// rays start within origin_bound of 0 and point at X up to the rounding of their direction.
-__global__ void __launch_bounds__(BLOCK) k_prep_ell_cone(const float4* __restrict__ ell, const uint32_t* __restrict__ k_of, uint32_t n, float x, float y, float z,
-                                                         float origin_bound, int reversed, float4* __restrict__ out) {
-    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
-    if (pos >= n) return;
-    const uint32_t k = k_of[pos];
-    const EllBound b = ell_bound(ell[static_cast<size_t>(k) * 6], ell[static_cast<size_t>(k) * 6 + 1], ell[static_cast<size_t>(k) * 6 + 2]);
-    float4 rec = make_float4(0.0f, 0.0f, 0.0f, -2.0f);   // keeps every ray
-    if (b.ok) {
-        const double eps = 5.9604644775390625e-8;
-        const double X[3] = {x, y, z};
-        const double to_c[3] = {b.c[0] - X[0], b.c[1] - X[1], b.c[2] - X[2]};
-        const double dist = sqrt(to_c[0] * to_c[0] + to_c[1] * to_c[1] + to_c[2] * to_c[2]);
-        const double x_max = fmax(fabs(X[0]), fmax(fabs(X[1]), fabs(X[2])));
-        const double c_len = sqrt(b.c[0] * b.c[0] + b.c[1] * b.c[1] + b.c[2] * b.c[2]);
-        const double D = reversed ? 1.7320508075688772 * origin_bound + c_len : dist;
-        const double r = ell_reach(b, D, reversed ? static_cast<double>(origin_bound) : x_max);
-        // a shadow ray's direction is a rounded quotient: its line misses X by up to 8 eps of the origin's distance from X
-        const double T_x = 2.0 * (1.7320508075688772 * origin_bound + x_max * 1.7320508075688772);
-        const double delta = reversed ? 2.0 * 8.0 * eps * T_x : 0.0;
-        const double reach = r + delta;
-        if (reach < 1.0e30 && dist > 1.01 * reach + 1.0e-30) {
-            const double theta = asin(reach / dist) + 1.0e-6;
-            if (theta < 1.5) {
-                const double cos_store = cos(theta) * (1.0 - 8.0 * eps) - 16.0 * eps;
-                const double sign = reversed ? -1.0 : 1.0;
-                rec = make_float4(static_cast<float>(sign * to_c[0] / dist), static_cast<float>(sign * to_c[1] / dist), static_cast<float>(sign * to_c[2] / dist),
-                                  nextafterf(static_cast<float>(cos_store), -2.0f));
-                if (!(rec.w > -1.0f && rec.w < 1.0f)) rec = make_float4(0.0f, 0.0f, 0.0f, -2.0f);
-            }
-        }
-    }
-    out[pos] = rec;
-}
-
 // box records of the ellipsoids: the hit point lies within ell_reach of the centre
 __global__ void __launch_bounds__(BLOCK) k_prep_ell_box(const float4* __restrict__ ell, const uint32_t* __restrict__ k_of, uint32_t n, float origin_bound, float4* __restrict__ out) {
     const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
@@ -1047,88 +744,33 @@ __global__ void __launch_bounds__(BLOCK) k_prep_ell_box(const float4* __restrict
 // the difference move perp2 by less than 11 eps D^2, and a direction longer than 1 lowers it by
 // (|d|^2 - 1) (oc.d)^2: reflected directions are not renormalised.  The records allow for
 // |d|^2 <= 1 + SPH_DIR_SLACK: a line the test accepts then passes within
-// sqrt(r^2 + (16 eps + SPH_DIR_SLACK) D^2) of the centre.  A ray whose direction is longer than that
-// (as evaluated: SPH_DIR_CHECK) has every radius enlarged by sphere_growth() in the scan of its
-// bounce (sphere_keeps_grown); where that is not done (cone records, shadow rays: directions
-// normalised a moment ago) a wave that holds such a ray keeps every sphere.  The distance the test returns can be negative (origin
-// inside the sphere); such a sphere is neither behind the origin for sphere_keeps nor outside a
-// cone of directions through the origin, so the pre-tests need no special case for it.
+// reach = sqrt(r^2 + (16 eps + SPH_DIR_SLACK) D^2) of the centre (sph_reach), and its hit point
+// o + t d, at sqrt(perp^2 + h^2) of the centre with h^2 = r^2 - perp2 as evaluated, within
+// sph_reach(reach): the noise enters twice (k_prep_sph_box).  A ray whose direction is longer than
+// that (as evaluated: SPH_DIR_CHECK) has every box enlarged by sphere_growth() in the closest-hit
+// scan (box_keeps_grown); the shadow scans, whose directions were normalised a moment ago, keep
+// every sphere for a wave that holds such a ray (a directional light of the caller's making).
+// The distance the test returns can be negative (hit_sphere: origin inside the sphere); the origin
+// then lies in the box, which the slab test keeps.
 constexpr float SPH_DIR_SLACK = 32.0f * 5.9604644775390625e-8f;
 constexpr float SPH_DIR_CHECK = 1.0f + 28.0f * 5.9604644775390625e-8f;   // |d|^2 as evaluated carries up to 3 eps
-// Enlargement of every sphere radius for a ray with direction d (not normalised), origins and centres
-// within max-norm B of 0: the excess e of |d|^2 over what the records allow adds e |oc|^2 <= 12 B^2 e
-// to the squared radius the test accepts.  The records' radius is reach + s with s the roundings of
-// the pre-test itself (s < 400 eps B): (sqrt(reach^2 + x) + s)^2 <= (reach + s)^2 + 1.5 x + 2 s^2,
-// so growing the record's radius by sqrt(1.5 x + 2 s^2) is enough.
+// Enlargement of every sphere's box for a ray with direction d (not normalised), origins and centres
+// within max-norm B of 0: the excess e of |d|^2 over what the records allow adds e |oc|^2 to the
+// squared distance perp^2 the test accepts and e (r^2 + D^2) to the hit point's offset along the
+// ray, together below 36 B^2 e (|oc|, D <= 2 sqrt(3) B, r <= B).  With s the other additive terms of
+// the box (s < 400 eps B): (sqrt(reach^2 + x) + s)^2 <= (reach + s)^2 + 1.5 x + 2 s^2; the growth
+// below is sqrt(72 B^2 e + 2 s^2), which covers 1.5 x.
 DEV float sphere_growth(V3 d, float B) {
     const float e = vdot(d, d) - SPH_DIR_CHECK;
     if (!(e > 0.0f)) return 0.0f;
-    return __builtin_sqrtf(fma_(e * 18.0018f, B * B, 1.2e-9f * (B * B))) * 1.0001f;
+    return __builtin_sqrtf(fma_(e * 72.0072f, B * B, 1.2e-9f * (B * B))) * 1.0001f;
 }
 __device__ double sph_reach(double r, double D) {
     const double eps = 5.9604644775390625e-8;   // 2^-24
     return sqrt(r * r * (1.0 + 4.0 * eps) + (16.0 * eps + SPH_DIR_SLACK) * D * D) * (1.0 + 1.0e-6) + 4.0 * eps * D;
 }
 __device__ bool sph_usable(float4 s) { return isfinite(s.x) && isfinite(s.y) && isfinite(s.z) && isfinite(s.w); }
-// sphere records (sphere_keeps) of the spheres, in cluster order
-__global__ void __launch_bounds__(BLOCK) k_prep_sph_sphere(const float4* __restrict__ sph, const uint32_t* __restrict__ k_of, uint32_t n, float origin_bound, float4* __restrict__ out) {
-    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
-    if (pos >= n) return;
-    const float4 s = sph[k_of[pos]];
-    float4 rec = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());   // keeps every ray
-    if (sph_usable(s)) {
-        const double eps = 5.9604644775390625e-8;
-        const double B = origin_bound;
-        const double c[3] = {s.x, s.y, s.z};
-        const double c_len = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
-        const double c_max = fmax(fabs(c[0]), fmax(fabs(c[1]), fabs(c[2])));
-        const double D = 1.7320508075688772 * B + c_len;
-        const double r = sph_reach(fabs(static_cast<double>(s.w)), D);
-        // as in k_prep_sphere: the pre-test's re-normalised direction, m = o x d and c x d - m
-        const double T = 2.0 * (D + r);
-        const double r_tot = (r + 2.0 * (3.0 * eps * T + 2.0 * eps * c_max)) * (1.0 + 6.0 * eps) + 2.0 * 13.0 * eps * (c_max + B);
-        const double r2 = r_tot * r_tot * (1.0 + 1.0e-6);
-        if (r2 < 1.0e30 && c_max <= B) rec = make_float4(s.x, s.y, s.z, nextafterf(static_cast<float>(r2), __builtin_inff()));
-    }
-    out[pos] = rec;
-}
-// cone records (cone_keeps) of the spheres for rays through X; `reversed` as in k_prep_ell_cone
-__global__ void __launch_bounds__(BLOCK) k_prep_sph_cone(const float4* __restrict__ sph, const uint32_t* __restrict__ k_of, uint32_t n, float x, float y, float z,
-                                                         float origin_bound, int reversed, float4* __restrict__ out) {
-    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
-    if (pos >= n) return;
-    const float4 s = sph[k_of[pos]];
-    float4 rec = make_float4(0.0f, 0.0f, 0.0f, -2.0f);   // keeps every ray
-    if (sph_usable(s)) {
-        const double eps = 5.9604644775390625e-8;
-        const double X[3] = {x, y, z};
-        const double c[3] = {s.x, s.y, s.z};
-        const double to_c[3] = {c[0] - X[0], c[1] - X[1], c[2] - X[2]};
-        const double dist = sqrt(to_c[0] * to_c[0] + to_c[1] * to_c[1] + to_c[2] * to_c[2]);
-        const double x_max = fmax(fabs(X[0]), fmax(fabs(X[1]), fabs(X[2])));
-        const double c_len = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
-        const double D = reversed ? 1.7320508075688772 * origin_bound + c_len : dist;
-        const double r = sph_reach(fabs(static_cast<double>(s.w)), D);
-        // a shadow ray's direction is a rounded quotient: its line misses X by up to 8 eps of the origin's distance from X
-        const double T_x = 2.0 * (1.7320508075688772 * origin_bound + x_max * 1.7320508075688772);
-        const double delta = reversed ? 2.0 * 8.0 * eps * T_x : 0.0;
-        const double reach = r + delta;
-        if (reach < 1.0e30 && dist > 1.01 * reach + 1.0e-30) {
-            const double theta = asin(reach / dist) + 1.0e-6;
-            if (theta < 1.5) {
-                const double cos_store = cos(theta) * (1.0 - 8.0 * eps) - 16.0 * eps;
-                const double sign = reversed ? -1.0 : 1.0;
-                rec = make_float4(static_cast<float>(sign * to_c[0] / dist), static_cast<float>(sign * to_c[1] / dist), static_cast<float>(sign * to_c[2] / dist),
-                                  nextafterf(static_cast<float>(cos_store), -2.0f));
-                if (!(rec.w > -1.0f && rec.w < 1.0f)) rec = make_float4(0.0f, 0.0f, 0.0f, -2.0f);
-            }
-        }
-    }
-    out[pos] = rec;
-}
-
-// box records of the spheres.  The hit point o + t d of an accepted ray lies at sqrt(perp^2 + h^2) of the
-// centre, with h^2 = r^2 - perp2 as evaluated: the noise of perp2 enters twice.
+// box records of the spheres
 __global__ void __launch_bounds__(BLOCK) k_prep_sph_box(const float4* __restrict__ sph, const uint32_t* __restrict__ k_of, uint32_t n, float origin_bound, float4* __restrict__ out) {
     const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
     if (pos >= n) return;
@@ -1140,7 +782,7 @@ __global__ void __launch_bounds__(BLOCK) k_prep_sph_box(const float4* __restrict
         const double c_len = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
         const double D = 1.7320508075688772 * origin_bound + c_len;
         const double r1 = sph_reach(fabs(static_cast<double>(s.w)), D);
-        const double r = sph_reach(r1, D);
+        const double r = sph_reach(r1 * (1.0 + 1.0e-5), D);   // and the cross term 2 h (oc.d) (|d|^2 - 1) of the hit point's offset
         for (int i = 0; i < 3; ++i) { lo[i] = c[i] - r; hi[i] = c[i] + r; }
     }
     store_box(out, pos, lo, hi, ok);
@@ -1344,7 +986,10 @@ DEV ScanSplit scan_split(uint32_t n_rays, uint32_t rays_per_block, uint32_t n_pr
 // The hierarchy scans read the 16-byte top-node records straight from memory, one record per lane
 // (coalesced; the record arrays stay in L2).  A record the packet pre-test keeps is broadcast from
 // the lane that holds it with v_readlane.  Waves are independent: no LDS staging, no barriers.
-constexpr uint32_t SHADOW_CHECK_STEPS = 1;          // shadow scans drain and re-check "all blocked" every so many steps of 64 top nodes
+#ifndef RT_SHADOW_CHECK_STEPS
+#define RT_SHADOW_CHECK_STEPS 1
+#endif
+constexpr uint32_t SHADOW_CHECK_STEPS = RT_SHADOW_CHECK_STEPS;          // shadow scans drain and re-check "all blocked" every so many steps of 64 top nodes
 DEV float readlane_f(float v, uint32_t l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), static_cast<int>(l))); }
 DEV float4 readlane4(float4 v, uint32_t l) { return make_float4(readlane_f(v.x, l), readlane_f(v.y, l), readlane_f(v.z, l), readlane_f(v.w, l)); }
 // The lanes of a wave hand data to each other through LDS (queue entries, blocked bits).  The
@@ -1360,7 +1005,10 @@ DEV void wave_sync() {
 // the ray is r*64 + lane of the lane that holds it (its slot is looked up in a per-wave table) and
 // the node is a top node, a cluster or a triangle position (hence at most 2^24 triangles).
 // A push adds up to 4 entries per lane.
-constexpr uint32_t QCAP = 384, PUSH_MAX = 256;
+#ifndef RT_QCAP
+#define RT_QCAP 384
+#endif
+constexpr uint32_t QCAP = RT_QCAP, PUSH_MAX = 256;
 #ifndef RT_WALK_BATCH
 #define RT_WALK_BATCH 4
 #endif
@@ -1399,27 +1047,26 @@ DEV float pretests_then_full(const DevScene& sc, const TriPair& f, V3 o, V3 d, u
 }
 
 // Closest hit of every live ray over the primitives of kind PRIM (0 triangles, 1 ellipsoids, 2 spheres).
-// MODE 0: brute force, every triangle through the full test (RT_FLAG_NO_FILTER): tiles of records
-// staged in LDS, broadcast reads, per-lane running minimum.
-// MODE 2 (rays from the eye, cone records) and 3 (rays with their own origin, sphere records):
-// the wave walks the bounding hierarchy of the kind.  Top nodes are tested one per lane against
-// the bound of the whole wave (packet test), then per ray; (ray, node) pairs go through three
-// per-wave queues in LDS (top node -> cluster -> leaf), each walked one pair per lane, and the
-// (ray, leaf) pairs that remain through the full test of the kind (for triangles after the
+// WALK = false: brute force, every triangle through the full test (RT_FLAG_NO_FILTER, small
+// scenes): tiles of records staged in LDS, broadcast reads, per-lane running minimum.
+// WALK = true: the wave walks the box hierarchy of the kind.  Top nodes are tested one per lane
+// against the bound of the whole wave (packet test), then per ray; (ray, node) pairs go through
+// three per-wave queues in LDS (top node -> cluster -> leaf), each walked one pair per lane, and
+// the (ray, leaf) pairs that remain through the full test of the kind (for triangles after the
 // two-stage pre-test).  Result: st.key[slot] / st.key_ell[slot] / st.key_sph[slot], by atomicMin.
-template <int R, int MODE, int PRIM>
+template <int R, bool WALK, int PRIM>
 __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc, State st, uint32_t bounce) {
-    static_assert(MODE != 0 || PRIM == 0, "the full-test mode of this kernel is for triangles");
+    static_assert(WALK || PRIM == 0, "the full-test mode of this kernel is for triangles");
     static_assert(64 * R <= PUSH_MAX && 64 * R <= 256, "a queue entry has 8 bits for the ray, a push adds at most PUSH_MAX entries");
     const Hierarchy& h = PRIM == 0 ? sc.th : (PRIM == 1 ? sc.eh : sc.sh);
     constexpr int WORDS = 4;
-    __shared__ float4 lds[MODE == 0 ? TILE_PRIMS * WORDS : 1];   // record tiles, full-test mode only
-    constexpr uint32_t WAVE_LDS = 3 * QCAP + 64 * R;   // per wave: (ray, top node), (ray, cluster) and (ray, triangle) queues, slot table
-    __shared__ uint32_t lds_queue[MODE == 0 ? 1 : (BLOCK / 64) * WAVE_LDS];
+    __shared__ float4 lds[WALK ? 1 : TILE_PRIMS * WORDS];   // record tiles, full-test mode only
+    constexpr uint32_t WAVE_LDS = 3 * QCAP + 64 * R;   // per wave: (ray, top node), (ray, cluster) and (ray, leaf) queues, slot table
+    __shared__ uint32_t lds_queue[WALK ? (BLOCK / 64) * WAVE_LDS : 1];
     const uint32_t n_rays = st.counts[bounce];
     const uint32_t* __restrict__ list_in = st.list[bounce & 1u];
     ScanSplit split;
-    if (MODE == 0) {
+    if (!WALK) {
         split = ScanSplit{blockIdx.x * (BLOCK * R), 0u, sc.n_tri, blockIdx.x * (BLOCK * R) < n_rays};
     } else {
         split = scan_split(n_rays, BLOCK * R, h.n_tops);
@@ -1427,7 +1074,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     if (!split.active) return;
     const uint32_t base = split.ray_base;
 
-    if (MODE == 0) {
+    if (!WALK) {
         uint32_t slot[R];
         bool valid[R];
         V3 o[R], d[R];
@@ -1464,7 +1111,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t* const q0 = lds_queue + wave * WAVE_LDS;      // (ray, top node)
     uint32_t* const q1 = q0 + QCAP;                        // (ray, cluster)
-    uint32_t* const q2 = q1 + QCAP;                        // (ray, triangle)
+    uint32_t* const q2 = q1 + QCAP;                        // (ray, leaf)
     uint32_t* const wave_slots = q2 + QCAP;                // slot of ray r*64 + lane
     uint32_t q0_count = 0, q1_count = 0, q2_count = 0, n_full = 0, n_queued = 0;
     unsigned long long n_pairs = 0;
@@ -1472,15 +1119,13 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     // a wave owns 64*R consecutive rays of the list, so that its packet bound is as narrow as the list allows
     uint32_t slot[R];
     bool valid[R];
-    V3 d[R], moment[R];
-    float along[R], grow[R];
-    BoxRay box_ray[R];      // MODE 4
+    float grow[R];
+    BoxRay box_ray[R];
     Packet packet;
-    bool unsafe = false;    // an origin outside the bound the sphere records were built for: keep everything
-    bool too_long = false;  // a direction longer than the bounds of the spheres allow for: likewise
-    constexpr bool GROWN = (MODE == 3 || MODE == 4) && PRIM == 2;   // spheres, rays of any direction length: the bounds grow with the length
+    bool unsafe = false;    // an origin outside the bound the box records were built for: keep everything
+    constexpr bool GROWN = PRIM == 2;   // spheres: the boxes grow with the length of the direction (sphere_growth)
     {
-        V3 o[R];
+        V3 o[R], d[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t i = base + wave * (64 * R) + r * 64 + lane;
@@ -1488,23 +1133,14 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             slot[r] = list_in[valid[r] ? i : base];
             o[r] = {st.ox[slot[r]], st.oy[slot[r]], st.oz[slot[r]]};
             d[r] = {st.dx[slot[r]], st.dy[slot[r]], st.dz[slot[r]]};
-            if (PRIM == 2 && !GROWN) too_long |= !(vdot(d[r], d[r]) <= SPH_DIR_CHECK);   // the sphere bounds allow for this much extra length only
-            if (MODE == 4) {
-                box_ray[r] = make_box_ray(o[r], d[r], FLT_MAX);
-                grow[r] = GROWN ? 2.0f * sphere_growth(d[r], sc.box_bound) : 0.0f;   // twice: the hit point, not only the line (k_prep_sph_box)
-                unsafe |= !(fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z))) <= sc.box_bound);
-                d[r] = normalise(d[r]);   // for the bound of the wave
-            } else {
-                grow[r] = GROWN ? sphere_growth(d[r], sc.origin_bound) : 0.0f;
-                if (MODE == 3) d[r] = normalise(d[r]);   // pre-test copy only: reflected directions drift off unit length
-                moment[r] = scross(o[r], d[r]);
-                along[r] = sphere_along(o[r], d[r], sc.origin_bound);
-                unsafe |= !(fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z))) <= sc.origin_bound);
-            }
+            box_ray[r] = make_box_ray(o[r], d[r], FLT_MAX);
+            grow[r] = GROWN ? sphere_growth(d[r], sc.box_bound) : 0.0f;
+            unsafe |= !(fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z))) <= sc.box_bound);
+            d[r] = normalise(d[r]);   // for the bound of the wave: reflected directions drift off unit length
             wave_slots[r * 64 + lane] = slot[r];
         }
-        packet = make_packet<R>(d, MODE >= 3 ? o : nullptr, valid);
-        if (GROWN) {   // a larger ball of origins is the same as larger spheres
+        packet = make_packet<R>(d, o, valid);
+        if (GROWN) {   // a larger ball of origins is the same as larger boxes
             float g = 0.0f;
 #pragma unroll
             for (int r = 0; r < R; ++r) g = fmaxf(g, valid[r] ? grow[r] : 0.0f);
@@ -1512,12 +1148,9 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
         }
         packet = uniform_packet(packet);
     }
-    const bool keep_all = (MODE >= 3 && __any(unsafe)) || (PRIM == 2 && __any(too_long));
-    const float4* __restrict__ top_stream = MODE == 2 ? h.top_eye : (MODE == 3 ? h.top_sphere : h.top_box);
-    const float4* __restrict__ cluster_stream = MODE == 2 ? h.cl_eye : (MODE == 3 ? h.cl_sphere : h.cl_box);
-    const float4* __restrict__ leaf_stream = MODE == 2 ? h.leaf_eye : (MODE == 3 ? h.leaf_sphere : h.leaf_box);
+    const bool keep_all = __any(unsafe);
 
-    // (ray, triangle) pairs: two-stage pre-test and full test, one pair per lane
+    // (ray, leaf) pairs: the full test of the kind (triangles: after the two-stage pre-test), one pair per lane
     auto drain2 = [&]() {
         wave_sync();
         if (PRIM == 0) {
@@ -1568,39 +1201,24 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             const uint32_t e = q_in[active ? i0 + lane : 0u];
             const uint32_t s = wave_slots[e >> 24], first = (e & NODE_MASK) * CLUSTER;
             const V3 o{st.ox[s], st.oy[s], st.oz[s]};
-            V3 dd{st.dx[s], st.dy[s], st.dz[s]};
+            const V3 dd{st.dx[s], st.dy[s], st.dz[s]};
             const BoxRay ray = make_box_ray(o, dd, FLT_MAX);
-            const float gr = GROWN ? (MODE == 4 ? 2.0f * sphere_growth(dd, sc.box_bound) : sphere_growth(dd, sc.origin_bound)) : 0.0f;
-            if (MODE == 3) dd = normalise(dd);
-            const V3 mm = scross(o, dd);
-            const float al = sphere_along(o, dd, sc.origin_bound);
+            const float gr = GROWN ? sphere_growth(dd, sc.box_bound) : 0.0f;
             const uint32_t last = n_child - 1u;
             static_assert(CLUSTER % WALK_BATCH == 0 && WALK_BATCH % 4 == 0, "the walk takes WALK_BATCH children at a time, pushed four by four");
 #pragma nounroll
             for (uint32_t t0 = 0; t0 < CLUSTER; t0 += WALK_BATCH) {     // WALK_BATCH records in flight per lane
+                float4 lo[WALK_BATCH], hi[WALK_BATCH];
+#pragma unroll
+                for (int u = 0; u < WALK_BATCH; ++u) {
+                    const size_t c = min(first + t0 + u, last);
+                    lo[u] = child[c * 2]; hi[u] = child[c * 2 + 1];
+                }
                 uint32_t keep_bits = 0;
-                if constexpr (MODE == 4) {
-                    float4 lo[WALK_BATCH], hi[WALK_BATCH];
 #pragma unroll
-                    for (int u = 0; u < WALK_BATCH; ++u) {
-                        const size_t c = min(first + t0 + u, last);
-                        lo[u] = child[c * 2]; hi[u] = child[c * 2 + 1];
-                    }
-#pragma unroll
-                    for (int u = 0; u < WALK_BATCH; ++u) {
-                        const bool keep = active && first + t0 + u <= last && ((GROWN ? box_keeps_grown(ray, lo[u], hi[u], gr) : box_keeps(ray, lo[u], hi[u])) || keep_all);
-                        keep_bits |= keep ? 1u << u : 0u;
-                    }
-                } else {
-                    float4 rec[WALK_BATCH];
-#pragma unroll
-                    for (int u = 0; u < WALK_BATCH; ++u) rec[u] = child[min(first + t0 + u, last)];
-#pragma unroll
-                    for (int u = 0; u < WALK_BATCH; ++u) {
-                        const bool keep = active && first + t0 + u <= last &&
-                                          ((MODE == 2 ? cone_keeps(dd, rec[u]) : (GROWN ? sphere_keeps_grown(dd, mm, al, rec[u], gr) : sphere_keeps(dd, mm, al, rec[u]))) || keep_all);
-                        keep_bits |= keep ? 1u << u : 0u;
-                    }
+                for (int u = 0; u < WALK_BATCH; ++u) {
+                    const bool keep = active && first + t0 + u <= last && ((GROWN ? box_keeps_grown(ray, lo[u], hi[u], gr) : box_keeps(ray, lo[u], hi[u])) || keep_all);
+                    keep_bits |= keep ? 1u << u : 0u;
                 }
 #pragma nounroll
                 for (uint32_t half = 0; half < WALK_BATCH / 4; ++half) {     // not unrolled: one copy of the code behind drain_out
@@ -1616,31 +1234,23 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
         wave_sync();
         in_count = 0;
     };
-    auto drain1 = [&]() { walk(q1, q1_count, leaf_stream, h.n, q2, q2_count, drain2); };
-    auto drain0 = [&]() { walk(q0, q0_count, cluster_stream, h.n_clusters, q1, q1_count, drain1); };
+    auto drain1 = [&]() { walk(q1, q1_count, h.leaf_box, h.n, q2, q2_count, drain2); };
+    auto drain0 = [&]() { walk(q0, q0_count, h.cl_box, h.n_clusters, q1, q1_count, drain1); };
 
     wave_sync();
     for (uint32_t c0 = split.first_prim; c0 < split.end_prim; c0 += 64) {
         const size_t mine_at = min(c0 + lane, split.end_prim - 1u);
-        const float4 mine = top_stream[MODE == 4 ? mine_at * 2 : mine_at];
-        const float4 mine_hi = MODE == 4 ? top_stream[mine_at * 2 + 1] : mine;
-        const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine) : packet_sphere_keeps(packet, MODE == 4 ? box_sphere(mine, mine_hi) : mine);
+        const float4 mine_lo = h.top_box[mine_at * 2], mine_hi = h.top_box[mine_at * 2 + 1];
+        const bool reach = packet_sphere_keeps(packet, box_sphere(mine_lo, mine_hi));
         unsigned long long mask = __ballot((reach || keep_all) && c0 + lane < split.end_prim);
         while (mask) {
             const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mask));
             mask &= mask - 1ull;
-            const float4 c = readlane4(mine, bit);
+            const float4 lo = readlane4(mine_lo, bit), hi = readlane4(mine_hi, bit);
             uint32_t keep_bits = 0;
-            if constexpr (MODE == 4) {
-                const float4 c_hi = readlane4(mine_hi, bit);
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    keep_bits |= ((GROWN ? box_keeps_grown(box_ray[r], c, c_hi, grow[r]) : box_keeps(box_ray[r], c, c_hi)) || keep_all) && valid[r] ? 1u << r : 0u;
-            } else {
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    keep_bits |= ((MODE == 2 ? cone_keeps(d[r], c) : (GROWN ? sphere_keeps_grown(d[r], moment[r], along[r], c, grow[r]) : sphere_keeps(d[r], moment[r], along[r], c))) || keep_all) && valid[r] ? 1u << r : 0u;
-            }
+            for (int r = 0; r < R; ++r)
+                keep_bits |= ((GROWN ? box_keeps_grown(box_ray[r], lo, hi, grow[r]) : box_keeps(box_ray[r], lo, hi)) || keep_all) && valid[r] ? 1u << r : 0u;
             if (__any(keep_bits != 0u)) {
                 if (q0_count + PUSH_MAX > QCAP) drain0();
                 push_bits(q0, q0_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
@@ -1654,7 +1264,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     if (lane == 0 && n_pairs) atomicAdd(stat_slot(st, ST_PAIR_PRETESTS), n_pairs);
     if (lane == 0 && n_queued) atomicAdd(stat_slot(st, ST_QUEUED), static_cast<unsigned long long>(n_queued));
     {   // FLOP executed in per-ray tests (n_full is per lane; the others are wave totals)
-        constexpr unsigned long long CHILD = MODE == 2 ? 6 : (MODE == 3 ? 18 : 24), LEAF = PRIM == 0 ? 40 : (PRIM == 1 ? 95 : 19), FULL = PRIM == 0 ? 54 : 0;
+        constexpr unsigned long long CHILD = 24, LEAF = PRIM == 0 ? 40 : (PRIM == 1 ? 95 : 19), FULL = PRIM == 0 ? 54 : 0;
         block_add_stat(stat_slot(st, ST_FLOP), FULL * n_full + (lane == 0 ? CHILD * n_pairs + LEAF * n_queued : 0ull));
     }
 }
@@ -1897,24 +1507,22 @@ DEV ShadowRay make_shadow_ray(const State& st, uint32_t slot, bool point, V3 lv)
 }
 
 // Any-hit of every hit point toward light first_light + blockIdx.y over the primitives of kind PRIM.
-// MODE 0: brute force over the triangles; 2: cone records of that point light (lights
-// first_light.. are point lights then); 3: sphere records (any light; used for the directional
-// one).  Queues as in k_closest_scan; a (ray, leaf) pair that blocks sets the ray's bit in LDS,
-// which the lane that holds the ray picks up after the drain; the wave stops when all its rays
-// are blocked.
-template <int R, int MODE, int PRIM>
+// WALK = false: brute force over the triangles.  WALK = true: the box hierarchy of the kind, queues
+// as in k_closest_scan; a (ray, leaf) pair that blocks sets the ray's bit in LDS, which the lane
+// that holds the ray picks up after the drain; the wave stops when all its rays are blocked.
+template <int R, bool WALK, int PRIM>
 __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
-    static_assert(MODE != 0 || PRIM == 0, "the full-test mode of this kernel is for triangles");
+    static_assert(WALK || PRIM == 0, "the full-test mode of this kernel is for triangles");
     static_assert(64 * R <= PUSH_MAX && 64 * R <= 256, "a queue entry has 8 bits for the ray, a push adds at most PUSH_MAX entries");
     const Hierarchy& h = PRIM == 0 ? sc.th : (PRIM == 1 ? sc.eh : sc.sh);
     constexpr int WORDS = 4;
-    __shared__ float4 lds[MODE == 0 ? TILE_PRIMS * WORDS : 1];   // record tiles, full-test mode only
-    constexpr uint32_t WAVE_LDS = 3 * QCAP + 64 * R;   // per wave: (ray, top node), (ray, cluster) and (ray, triangle) queues, slot table
-    __shared__ uint32_t lds_queue[MODE == 0 ? 1 : (BLOCK / 64) * WAVE_LDS];
+    __shared__ float4 lds[WALK ? 1 : TILE_PRIMS * WORDS];   // record tiles, full-test mode only
+    constexpr uint32_t WAVE_LDS = 3 * QCAP + 64 * R;   // per wave: (ray, top node), (ray, cluster) and (ray, leaf) queues, slot table
+    __shared__ uint32_t lds_queue[WALK ? (BLOCK / 64) * WAVE_LDS : 1];
     __shared__ uint32_t lds_blocked[BLOCK];   // bit r: ray r of that thread is blocked (set by drains)
     const uint32_t n_rays = st.counts[bounce + 1];
     ScanSplit split;
-    if (MODE == 0) {
+    if (!WALK) {
         split = ScanSplit{blockIdx.x * (BLOCK * R), 0u, sc.n_tri, blockIdx.x * (BLOCK * R) < n_rays};
     } else {
         split = scan_split(n_rays, BLOCK * R, h.n_tops);
@@ -1931,9 +1539,8 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     // a wave owns 64*R consecutive rays of the list (see k_closest_scan)
     uint32_t slot[R];
     bool valid[R], blocked[R];
-    V3 d[R], moment[R];
-    float along[R];
-    BoxRay box_ray[R];      // MODE 4
+    V3 d[R];
+    BoxRay box_ray[R];
     // the segment toward a point light ends at the light for triangles and spheres (their tests compare the distance itself);
     // the ellipsoid test compares in its own space, so its boxes are tested against the whole half line
     constexpr bool LIMITED = PRIM != 1;
@@ -1949,19 +1556,17 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             const ShadowRay s = make_shadow_ray(st, slot[r], point, lv);
             o[r] = s.o;
             d[r] = s.d;
-            moment[r] = scross(s.o, s.d);
-            along[r] = sphere_along(s.o, s.d, sc.origin_bound);
-            if (MODE == 4) box_ray[r] = make_box_ray(s.o, s.d, LIMITED ? s.limit : FLT_MAX);
-            unsafe |= !(fmaxf(fabsf(s.o.x), fmaxf(fabsf(s.o.y), fabsf(s.o.z))) <= sc.origin_bound);
-            if (!point) unsafe |= !(vdot(s.d, s.d) <= SPH_DIR_CHECK);   // a directional light's direction is the caller's: the pre-tests need unit length
+            box_ray[r] = make_box_ray(s.o, s.d, LIMITED ? s.limit : FLT_MAX);
+            unsafe |= !(fmaxf(fabsf(s.o.x), fmaxf(fabsf(s.o.y), fabsf(s.o.z))) <= sc.box_bound);
+            if (!point) unsafe |= !(vdot(s.d, s.d) <= SPH_DIR_CHECK);   // a directional light's direction is the caller's: the pre-tests and the spheres' boxes need unit length
             blocked[r] = (st.blocked[slot[r]] & light_bit) != 0u;
-            if (MODE != 0) lds_queue[(threadIdx.x >> 6) * WAVE_LDS + 3 * QCAP + r * 64 + (threadIdx.x & 63u)] = slot[r];
+            if (WALK) lds_queue[(threadIdx.x >> 6) * WAVE_LDS + 3 * QCAP + r * 64 + (threadIdx.x & 63u)] = slot[r];
         }
-        if (MODE != 0) packet = uniform_packet(make_packet<R>(d, MODE >= 3 ? o : nullptr, valid));
+        if (WALK) packet = uniform_packet(make_packet<R>(d, o, valid));
     }
     lds_blocked[threadIdx.x] = 0u;
     wave_sync();
-    const bool keep_all = MODE != 0 && __any(unsafe);
+    const bool keep_all = WALK && __any(unsafe);
     auto wave_done = [&]() {
         bool all = true;
 #pragma unroll
@@ -1972,19 +1577,15 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t* const q0 = lds_queue + wave * WAVE_LDS;      // (ray, top node)
     uint32_t* const q1 = q0 + QCAP;                        // (ray, cluster)
-    uint32_t* const q2 = q1 + QCAP;                        // (ray, triangle)
+    uint32_t* const q2 = q1 + QCAP;                        // (ray, leaf)
     uint32_t* const wave_slots = q2 + QCAP;                // slot of ray r*64 + lane
     uint32_t q0_count = 0, q1_count = 0, q2_count = 0, n_full = 0, n_queued = 0;
     unsigned long long n_pairs = 0;
-    const size_t light_index = MODE == 2 ? light - sc.has_directional : 0u;
-    const float4* __restrict__ top_stream = MODE == 2 ? h.top_light + light_index * h.n_tops : (MODE == 4 ? h.top_box : h.top_sphere);
-    const float4* __restrict__ cluster_stream = MODE == 2 ? h.cl_light + light_index * h.n_clusters : (MODE == 4 ? h.cl_box : h.cl_sphere);
-    const float4* __restrict__ member_stream = MODE == 2 ? h.leaf_light + light_index * h.n : (MODE == 4 ? h.leaf_box : h.leaf_sphere);
     // blocked bits of the wave's rays live in lds_blocked[thread that holds the ray], bit r; ray = r*64 + lane
     auto ray_blocked = [&](uint32_t ray) {
         return ((__hip_atomic_load(&lds_blocked[wave * 64u + (ray & 63u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> (ray >> 6)) & 1u) != 0u;
     };
-    // (ray, triangle) pairs: two-stage pre-test and full test, one pair per lane; a pair that blocks sets its ray's bit
+    // (ray, leaf) pairs: the full test of the kind (triangles: after the two-stage pre-test), one pair per lane; a pair that blocks sets its ray's bit
     auto drain2 = [&]() {
         wave_sync();
         if (PRIM == 0) {
@@ -2033,35 +1634,22 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             const uint32_t first = (e & NODE_MASK) * CLUSTER;
             active = active && !ray_blocked(e >> 24);
             const ShadowRay s = make_shadow_ray(st, wave_slots[e >> 24], point, lv);
-            const V3 mm = scross(s.o, s.d);
-            const float al = sphere_along(s.o, s.d, sc.origin_bound);
             const BoxRay ray = make_box_ray(s.o, s.d, LIMITED ? s.limit : FLT_MAX);
             const uint32_t last = n_child - 1u;
             static_assert(CLUSTER % WALK_BATCH == 0 && WALK_BATCH % 4 == 0, "the walk takes WALK_BATCH children at a time, pushed four by four");
 #pragma nounroll
             for (uint32_t t0 = 0; t0 < CLUSTER; t0 += WALK_BATCH) {     // WALK_BATCH records in flight per lane
+                float4 lo[WALK_BATCH], hi[WALK_BATCH];
+#pragma unroll
+                for (int u = 0; u < WALK_BATCH; ++u) {
+                    const size_t c = min(first + t0 + u, last);
+                    lo[u] = child[c * 2]; hi[u] = child[c * 2 + 1];
+                }
                 uint32_t keep_bits = 0;
-                if constexpr (MODE == 4) {
-                    float4 lo[WALK_BATCH], hi[WALK_BATCH];
 #pragma unroll
-                    for (int u = 0; u < WALK_BATCH; ++u) {
-                        const size_t c = min(first + t0 + u, last);
-                        lo[u] = child[c * 2]; hi[u] = child[c * 2 + 1];
-                    }
-#pragma unroll
-                    for (int u = 0; u < WALK_BATCH; ++u) {
-                        const bool keep = active && first + t0 + u <= last && (box_keeps(ray, lo[u], hi[u]) || keep_all);
-                        keep_bits |= keep ? 1u << u : 0u;
-                    }
-                } else {
-                    float4 rec[WALK_BATCH];
-#pragma unroll
-                    for (int u = 0; u < WALK_BATCH; ++u) rec[u] = child[min(first + t0 + u, last)];
-#pragma unroll
-                    for (int u = 0; u < WALK_BATCH; ++u) {
-                        const bool keep = active && first + t0 + u <= last && ((MODE == 2 ? cone_keeps(s.d, rec[u]) : sphere_keeps(s.d, mm, al, rec[u])) || keep_all);
-                        keep_bits |= keep ? 1u << u : 0u;
-                    }
+                for (int u = 0; u < WALK_BATCH; ++u) {
+                    const bool keep = active && first + t0 + u <= last && (box_keeps(ray, lo[u], hi[u]) || keep_all);
+                    keep_bits |= keep ? 1u << u : 0u;
                 }
 #pragma nounroll
                 for (uint32_t half = 0; half < WALK_BATCH / 4; ++half) {     // not unrolled: one copy of the code behind drain_out
@@ -2077,13 +1665,13 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
         wave_sync();
         in_count = 0;
     };
-    auto drain1 = [&]() { walk(q1, q1_count, member_stream, h.n, q2, q2_count, drain2); };
-    auto drain0 = [&]() { walk(q0, q0_count, cluster_stream, h.n_clusters, q1, q1_count, drain1); };
+    auto drain1 = [&]() { walk(q1, q1_count, h.leaf_box, h.n, q2, q2_count, drain2); };
+    auto drain0 = [&]() { walk(q0, q0_count, h.cl_box, h.n_clusters, q1, q1_count, drain1); };
 
     unsigned long long wave_tests = 0;   // tests spent on still-undecided rays (wave-uniform)
     bool done = wave_done();
     const float4* __restrict__ tri_stream = sc.tri;   // full-test mode
-    if (MODE == 0) {
+    if (!WALK) {
         for (uint32_t first = split.first_prim; first < split.end_prim; first += TILE_PRIMS) {
             const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), split.end_prim - first);
             if (__syncthreads_and(done)) break;
@@ -2118,24 +1706,17 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
         uint32_t live = live_rays(), steps = 0;
         for (uint32_t c0 = split.first_prim; c0 < split.end_prim && live != 0; c0 += 64) {
             const size_t mine_at = min(c0 + lane, split.end_prim - 1u);
-            const float4 mine = top_stream[MODE == 4 ? mine_at * 2 : mine_at];
-            const float4 mine_hi = MODE == 4 ? top_stream[mine_at * 2 + 1] : mine;
+            const float4 mine_lo = h.top_box[mine_at * 2], mine_hi = h.top_box[mine_at * 2 + 1];
             wave_tests += static_cast<unsigned long long>(min(h.n, min(c0 + 64u, split.end_prim) * (CLUSTER * CLUSTER)) - c0 * (CLUSTER * CLUSTER)) * live;
-            const bool reach = MODE == 2 ? packet_cone_keeps(packet, mine) : packet_sphere_keeps(packet, MODE == 4 ? box_sphere(mine, mine_hi) : mine);
+            const bool reach = packet_sphere_keeps(packet, box_sphere(mine_lo, mine_hi));
             unsigned long long mask = __ballot((reach || keep_all) && c0 + lane < split.end_prim);
             while (mask) {
                 const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mask));
                 mask &= mask - 1ull;
-                const float4 c = readlane4(mine, bit);
+                const float4 lo = readlane4(mine_lo, bit), hi = readlane4(mine_hi, bit);
                 uint32_t keep_bits = 0;
-                if constexpr (MODE == 4) {
-                    const float4 c_hi = readlane4(mine_hi, bit);
 #pragma unroll
-                    for (int r = 0; r < R; ++r) keep_bits |= (box_keeps(box_ray[r], c, c_hi) || keep_all) && valid[r] && !blocked[r] ? 1u << r : 0u;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) keep_bits |= ((MODE == 2 ? cone_keeps(d[r], c) : sphere_keeps(d[r], moment[r], along[r], c)) || keep_all) && valid[r] && !blocked[r] ? 1u << r : 0u;
-                }
+                for (int r = 0; r < R; ++r) keep_bits |= (box_keeps(box_ray[r], lo, hi) || keep_all) && valid[r] && !blocked[r] ? 1u << r : 0u;
                 if (__any(keep_bits != 0u)) {
                     if (q0_count + PUSH_MAX > QCAP) drain0();
                     push_bits(q0, q0_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
@@ -2149,11 +1730,11 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     for (int r = 0; r < R; ++r)
         if (valid[r] && blocked[r]) atomicOr(&st.blocked[slot[r]], light_bit);
     if ((threadIdx.x & 63u) == 0 && wave_tests) atomicAdd(stat_slot(st, PRIM == 0 ? ST_SHADOW_TESTS_TRI : (PRIM == 1 ? ST_SHADOW_TESTS_ELL : ST_SHADOW_TESTS_SPH)), wave_tests);
-    if (MODE != 0 && PRIM == 0) block_add_stat(stat_slot(st, ST_FULL_TESTS), n_full);
+    if (WALK && PRIM == 0) block_add_stat(stat_slot(st, ST_FULL_TESTS), n_full);
     if ((threadIdx.x & 63u) == 0 && n_pairs) atomicAdd(stat_slot(st, ST_PAIR_PRETESTS_SHADOW), n_pairs);
     if ((threadIdx.x & 63u) == 0 && n_queued) atomicAdd(stat_slot(st, ST_QUEUED_SHADOW), static_cast<unsigned long long>(n_queued));
-    if (MODE != 0) {   // FLOP executed in per-ray tests (n_full is per lane; the others are wave totals)
-        constexpr unsigned long long CHILD = MODE == 2 ? 6 : (MODE == 3 ? 18 : 24), LEAF = PRIM == 0 ? 40 : (PRIM == 1 ? 71 : 19), FULL = PRIM == 0 ? 54 : 0;
+    if (WALK) {   // FLOP executed in per-ray tests (n_full is per lane; the others are wave totals)
+        constexpr unsigned long long CHILD = 24, LEAF = PRIM == 0 ? 40 : (PRIM == 1 ? 71 : 19), FULL = PRIM == 0 ? 54 : 0;
         block_add_stat(stat_slot(st, ST_FLOP_SHADOW), FULL * n_full + ((threadIdx.x & 63u) == 0 ? CHILD * n_pairs + LEAF * n_queued : 0ull));
     }
 }
@@ -2409,12 +1990,9 @@ uint32_t rank_tiles(const rt_render_params& p) {
 struct rt_scene {
     DevScene dev;
     std::vector<void*> allocations;
-    // cone records for rays from the eye, rebuilt when the eye moves (one render at a time per scene)
-    struct EyeRecords { float4 *leaf = nullptr, *cl = nullptr, *top = nullptr; };
-    mutable EyeRecords eye_tri, eye_ell, eye_sph;
-    mutable float eye[3] = {0, 0, 0};
-    mutable bool eye_valid = false;
-    mutable float box_bound = 0.0f;    // bound of ray origins the box records were built for (0: not built yet)
+    // bound of ray origins the box records were built for; grows (records rebuilt) when a camera's eye lies outside it:
+    // one render at a time per scene
+    mutable float box_bound = 0.0f;
     bool directional_is_unit = true;   // |direction|^2 <= 1 + 20 * 2^-24: the shadow scans toward it may use the pre-tests
 };
 
@@ -2503,37 +2081,17 @@ void build_boxes(const rt_scene* scene, float bound, hipStream_t stream) {
     }
     scene->box_bound = bound;
 }
-// Which ray classes walk the box records instead of the cone / sphere records: bit 0 rays from the eye,
-// 1 reflected rays, 2 shadow rays toward point lights, 3 toward the directional light.
-// RT_AMD_BOX in the environment overrides the default (tuning).
-constexpr uint32_t BOX_DEFAULT = 15;
-uint32_t box_classes() {
-    static const uint32_t value = [] {
-        const char* e = std::getenv("RT_AMD_BOX");
-        return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : BOX_DEFAULT;
-    }();
-    return value;
-}
-
 const Hierarchy& hierarchy_of(const DevScene& sc, int prim) { return prim == 0 ? sc.th : (prim == 1 ? sc.eh : sc.sh); }
-// hierarchy scans of one kind: rays per lane (1 or 2) and record kind (cone records for rays through a common point, else sphere records)
+// box-hierarchy scans of one kind, one or two rays per lane
 template <int PRIM>
-void launch_closest_scan(bool two, bool eye_rays, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b) {
-    if (box_classes() & (eye_rays ? 1u : 2u)) {
-        if (two) hipLaunchKernelGGL((k_closest_scan<2, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b); else hipLaunchKernelGGL((k_closest_scan<1, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b);
-        return;
-    }
-    if (eye_rays) { if (two) hipLaunchKernelGGL((k_closest_scan<2, 2, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b); else hipLaunchKernelGGL((k_closest_scan<1, 2, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b); }
-    else { if (two) hipLaunchKernelGGL((k_closest_scan<2, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b); else hipLaunchKernelGGL((k_closest_scan<1, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b); }
+void launch_closest_scan(bool two, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b) {
+    if (two) hipLaunchKernelGGL((k_closest_scan<2, true, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b);
+    else hipLaunchKernelGGL((k_closest_scan<1, true, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b);
 }
 template <int PRIM>
-void launch_shadow_scan(bool two, bool point_lights, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b, uint32_t first_light, uint32_t group_first) {
-    if (box_classes() & (point_lights ? 4u : 8u)) {
-        if (two) hipLaunchKernelGGL((k_shadow_scan<2, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first);
-        return;
-    }
-    if (point_lights) { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 2, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 2, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first); }
-    else { if (two) hipLaunchKernelGGL((k_shadow_scan<2, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first); else hipLaunchKernelGGL((k_shadow_scan<1, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first); }
+void launch_shadow_scan(bool two, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b, uint32_t first_light, uint32_t group_first) {
+    if (two) hipLaunchKernelGGL((k_shadow_scan<2, true, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first);
+    else hipLaunchKernelGGL((k_shadow_scan<1, true, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first);
 }
 
 int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_render_params* prm, uint8_t* tiles_dev,
@@ -2558,31 +2116,6 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
 
     DevScene sc = scene->dev;
     hipStream_t stream = g_lib.stream;
-    if (!scene->eye_valid || std::memcmp(scene->eye, cam->eye, sizeof scene->eye) != 0) {
-        // the records for rays from the eye depend on where the eye is
-        auto rebuild = [&](const Hierarchy& h, const rt_scene::EyeRecords& e) {
-            hipLaunchKernelGGL(k_prep_cluster_cone, dim3(ceil_div(h.n_clusters, BLOCK)), dim3(BLOCK), 0, stream, static_cast<const float4*>(e.leaf), h.n, h.n_clusters, e.cl);
-            hipLaunchKernelGGL(k_prep_cluster_cone, dim3(ceil_div(h.n_tops, BLOCK)), dim3(BLOCK), 0, stream, static_cast<const float4*>(e.cl), h.n_clusters, h.n_tops, e.top);
-        };
-        if (sc.n_tri) {
-            hipLaunchKernelGGL(k_prep_cone, dim3(ceil_div(sc.n_tri, BLOCK)), dim3(BLOCK), 0, stream, sc.tri, sc.th.k_of, sc.n_tri,
-                               cam->eye[0], cam->eye[1], cam->eye[2], sc.origin_bound, 0, scene->eye_tri.leaf);
-            rebuild(sc.th, scene->eye_tri);
-        }
-        if (sc.n_ell) {
-            hipLaunchKernelGGL(k_prep_ell_cone, dim3(ceil_div(sc.n_ell, BLOCK)), dim3(BLOCK), 0, stream, sc.ell, sc.eh.k_of, sc.n_ell,
-                               cam->eye[0], cam->eye[1], cam->eye[2], sc.origin_bound, 0, scene->eye_ell.leaf);
-            rebuild(sc.eh, scene->eye_ell);
-        }
-        if (sc.n_sph) {
-            hipLaunchKernelGGL(k_prep_sph_cone, dim3(ceil_div(sc.n_sph, BLOCK)), dim3(BLOCK), 0, stream, sc.sph, sc.sh.k_of, sc.n_sph,
-                               cam->eye[0], cam->eye[1], cam->eye[2], sc.origin_bound, 0, scene->eye_sph.leaf);
-            rebuild(sc.sh, scene->eye_sph);
-        }
-        HIP_TRY(hipGetLastError());
-        std::memcpy(scene->eye, cam->eye, sizeof scene->eye);
-        scene->eye_valid = true;
-    }
     {   // the box records must hold for the eye as an origin too
         float need = sc.origin_bound;
         for (int i = 0; i < 3; ++i) need = std::fmax(need, 1.001f * std::fabs(cam->eye[i]) + 1.0e-3f);
@@ -2593,9 +2126,6 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         }
         sc.box_bound = scene->box_bound;
     }
-    sc.th.leaf_eye = scene->eye_tri.leaf; sc.th.cl_eye = scene->eye_tri.cl; sc.th.top_eye = scene->eye_tri.top;
-    sc.eh.leaf_eye = scene->eye_ell.leaf; sc.eh.cl_eye = scene->eye_ell.cl; sc.eh.top_eye = scene->eye_ell.top;
-    sc.sh.leaf_eye = scene->eye_sph.leaf; sc.sh.cl_eye = scene->eye_sph.cl; sc.sh.top_eye = scene->eye_sph.top;
     Frame f;
     std::memcpy(f.eye, cam->eye, sizeof f.eye);
     std::memcpy(f.bi, cam->basis_i, sizeof f.bi);
@@ -2621,7 +2151,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     // per kind (0 triangles, 1 ellipsoids, 2 spheres): walk its hierarchy, or scan it by brute force
     const uint32_t below = (prm->flags & RT_FLAG_WALK_ALL) ? 0u : brute_force_below();
     const bool walk[3] = {filter && sc.th.n > below, filter && sc.eh.n > below, filter && sc.sh.n > below};
-    if (n_lanes > 1) {   // the other lanes start when the eye records and the cleared counters are ready
+    if (n_lanes > 1) {   // the other lanes start when the box records and the cleared counters are ready
         HIP_TRY(hipEventRecord(g_lib.lanes_fork, g_lib.lanes[0].stream));
         for (uint32_t l = 1; l < n_lanes; ++l) HIP_TRY(hipStreamWaitEvent(g_lib.lanes[l].stream, g_lib.lanes_fork, 0));
     }
@@ -2659,13 +2189,13 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
             auto hierarchy_scan = [&](int prim) {   // one or two rays per lane (TOPS_FOR_TWO_RAYS)
                 const bool two = hierarchy_of(sc, prim).n_tops > TOPS_FOR_TWO_RAYS;
                 const dim3 grid(blocks_for(two ? 2 : 1));
-                if (prim == 0) launch_closest_scan<0>(two, b == 0, grid, on, sc, sb, b);
-                else if (prim == 1) launch_closest_scan<1>(two, b == 0, grid, on, sc, sb, b);
-                else launch_closest_scan<2>(two, b == 0, grid, on, sc, sb, b);
+                if (prim == 0) launch_closest_scan<0>(two, grid, on, sc, sb, b);
+                else if (prim == 1) launch_closest_scan<1>(two, grid, on, sc, sb, b);
+                else launch_closest_scan<2>(two, grid, on, sc, sb, b);
             };
             timed(timer, 0, on, [&] {
                 if (sc.n_tri) {
-                    if (!walk[0]) hipLaunchKernelGGL((k_closest_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
+                    if (!walk[0]) hipLaunchKernelGGL((k_closest_scan<RAYS_PER_LANE, false, 0>), dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
                     else hierarchy_scan(0);
                 }
                 if (sc.n_sph) {
@@ -2678,12 +2208,13 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                 }
             });
         };
-        auto shadow_scan = [&](const State& sb, int prim, bool point_lights, uint32_t n, uint32_t b, uint32_t first_light, uint32_t group_first) {
+        // box-hierarchy shadow scan of one kind toward the n lights first_light..
+        auto shadow_scan = [&](const State& sb, int prim, uint32_t n, uint32_t b, uint32_t first_light, uint32_t group_first) {
             const bool two = hierarchy_of(sc, prim).n_tops > TOPS_FOR_TWO_RAYS;
             const dim3 grid(blocks_for(two ? 2 : 1), n);
-            if (prim == 0) launch_shadow_scan<0>(two, point_lights, grid, stream, sc, sb, b, first_light, group_first);
-            else if (prim == 1) launch_shadow_scan<1>(two, point_lights, grid, stream, sc, sb, b, first_light, group_first);
-            else launch_shadow_scan<2>(two, point_lights, grid, stream, sc, sb, b, first_light, group_first);
+            if (prim == 0) launch_shadow_scan<0>(two, grid, stream, sc, sb, b, first_light, group_first);
+            else if (prim == 1) launch_shadow_scan<1>(two, grid, stream, sc, sb, b, first_light, group_first);
+            else launch_shadow_scan<2>(two, grid, stream, sc, sb, b, first_light, group_first);
         };
 
         // Per bounce: closest-hit scans -> k_hit (which also writes the reflected ray) -> list compaction ->
@@ -2712,13 +2243,13 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
             } else {
                 for (uint32_t l0 = 0; l0 < sc.n_lights; l0 += 32) {
                     const uint32_t group = (sc.n_lights - l0 < 32) ? sc.n_lights - l0 : 32;
-                    // the directional light, if it is in this group, is light 0; the rest are point lights
+                    // the directional light, if it is in this group, is light 0
                     const uint32_t n_dir = (l0 == 0 && sc.has_directional) ? 1u : 0u;
                     const uint32_t n_pt = group - n_dir;
                     // brute-force shadow scan of one kind toward lights first.. (n of them)
                     auto brute_force = [&](int prim, uint32_t n, uint32_t first_light) {
                         const dim3 grid(scan_blocks, n);
-                        if (prim == 0) hipLaunchKernelGGL((k_shadow_scan<RAYS_PER_LANE, 0, 0>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
+                        if (prim == 0) hipLaunchKernelGGL((k_shadow_scan<RAYS_PER_LANE, false, 0>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                         else if (prim == 1) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                         else hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                     };
@@ -2726,11 +2257,15 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                         const uint32_t count[3] = {sc.n_tri, sc.n_ell, sc.n_sph};
                         for (int prim = 0; prim < 3; ++prim) {
                             if (count[prim] == 0) continue;
-                            if (!walk[prim]) { brute_force(prim, group, l0); continue; }
-                            // the pre-tests need a direction of unit length; the directional light's is the caller's
-                            if (n_dir && scene->directional_is_unit) shadow_scan(sb, prim, false, 1, b, l0, l0);
-                            else if (n_dir) brute_force(prim, 1, l0);
-                            if (n_pt) shadow_scan(sb, prim, true, n_pt, b, l0 + n_dir, l0);
+                            if (!walk[prim]) {
+                                brute_force(prim, group, l0);
+                            } else if (n_dir && !scene->directional_is_unit) {
+                                // the pre-tests need a direction of unit length; the directional light's is the caller's
+                                brute_force(prim, 1, l0);
+                                if (n_pt) shadow_scan(sb, prim, n_pt, b, l0 + 1, l0);
+                            } else {
+                                shadow_scan(sb, prim, group, b, l0, l0);
+                            }
                         }
                     });
                     hipLaunchKernelGGL(k_shade, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, sb, b, l0, group, (l0 + group == sc.n_lights) ? 1u : 0u);
@@ -2788,8 +2323,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
 // triangles is split at a multiple of CLUSTER*CLUSTER near its middle along its longest axis,
 // a smaller one at a multiple of CLUSTER, so that every aligned group of CLUSTER positions is one
 // leaf (a compact patch) and every aligned group of CLUSTER clusters one subtree.
-// Only the pre-test records are stored in this order; it decides which triangles share a bounding
-// record and nothing else, so any permutation gives the same image.
+// Only the box records and the triangles' pre-test records are stored in this order; it decides
+// which primitives share a box and nothing else, so any permutation gives the same image.
 std::vector<uint32_t> cluster_order(const std::vector<float>& centroid, const std::vector<uint8_t>& good) {
     const uint32_t n = static_cast<uint32_t>(good.size());
     std::vector<uint32_t> order, rejects;
@@ -2977,12 +2512,10 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     if (d.n_ell && desc->n_point_lights)
         hipLaunchKernelGGL(k_prep_ellipsoid_lights, dim3(ceil_div(d.n_ell, BLOCK)), dim3(BLOCK), 0, stream, ell, d.n_ell, raw_pl, static_cast<uint32_t>(desc->n_point_lights), ell_light);
 
-    // bounding records (see Hierarchy): cluster order on the host, leaf records per kind, then the two levels above
+    // box hierarchy of every kind (see Hierarchy): cluster order on the host; the boxes themselves by build_boxes below
     std::vector<uint32_t> orders[3];   // stay alive until the stream has been synchronised below
-    const size_t n_pl = desc->n_point_lights;
     for (int prim = 0; prim < 3; ++prim) {
         Hierarchy& h = prim == 0 ? d.th : (prim == 1 ? d.eh : d.sh);
-        rt_scene::EyeRecords& eye = prim == 0 ? s->eye_tri : (prim == 1 ? s->eye_ell : s->eye_sph);
         h.n = prim == 0 ? d.n_tri : (prim == 1 ? d.n_ell : d.n_sph);
         h.n_clusters = ceil_div(h.n, CLUSTER);
         h.n_tops = ceil_div(h.n_clusters, CLUSTER);
@@ -3001,45 +2534,18 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
         }
         orders[prim] = cluster_order(centroid, good);
         uint32_t* k_of;
-        float4 *leaf_light, *leaf_sphere, *cl_light, *cl_sphere, *top_light, *top_sphere;
-        if ((rc = upload(s, orders[prim].data(), orders[prim].size(), &k_of))) return fail(rc);
-        if ((rc = upload<float4>(s, nullptr, h.n, &eye.leaf))) return fail(rc);
-        if ((rc = upload<float4>(s, nullptr, h.n_clusters, &eye.cl))) return fail(rc);
-        if ((rc = upload<float4>(s, nullptr, h.n_tops, &eye.top))) return fail(rc);
-        if ((rc = upload<float4>(s, nullptr, h.n * n_pl, &leaf_light))) return fail(rc);
-        if ((rc = upload<float4>(s, nullptr, h.n_clusters * n_pl, &cl_light))) return fail(rc);
-        if ((rc = upload<float4>(s, nullptr, h.n_tops * n_pl, &top_light))) return fail(rc);
-        if ((rc = upload<float4>(s, nullptr, h.n, &leaf_sphere))) return fail(rc);
-        if ((rc = upload<float4>(s, nullptr, h.n_clusters, &cl_sphere))) return fail(rc);
-        if ((rc = upload<float4>(s, nullptr, h.n_tops, &top_sphere))) return fail(rc);
         float4 *leaf_box, *cl_box, *top_box;
+        if ((rc = upload(s, orders[prim].data(), orders[prim].size(), &k_of))) return fail(rc);
         if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n) * 2, &leaf_box))) return fail(rc);
         if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n_clusters) * 2, &cl_box))) return fail(rc);
         if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n_tops) * 2, &top_box))) return fail(rc);
-        h.leaf_box = leaf_box; h.cl_box = cl_box; h.top_box = top_box;
         h.k_of = k_of;
-        h.leaf_light = leaf_light; h.cl_light = cl_light; h.top_light = top_light;
-        h.leaf_sphere = leaf_sphere; h.cl_sphere = cl_sphere; h.top_sphere = top_sphere;
-        const dim3 leaf_grid(ceil_div(h.n, BLOCK)), cl_grid(ceil_div(h.n_clusters, BLOCK)), top_grid(ceil_div(h.n_tops, BLOCK));
+        h.leaf_box = leaf_box; h.cl_box = cl_box; h.top_box = top_box;
         if (prim == 0) {
             float4* trif_pos;
             if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n) * 4, &trif_pos))) return fail(rc);
-            hipLaunchKernelGGL(k_reorder_pretest_records, leaf_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(trif), h.k_of, h.n, trif_pos);
+            hipLaunchKernelGGL(k_reorder_pretest_records, dim3(ceil_div(h.n, BLOCK)), dim3(BLOCK), 0, stream, static_cast<const float4*>(trif), h.k_of, h.n, trif_pos);
             d.trif_pos = trif_pos;
-        }
-        if (prim == 0) hipLaunchKernelGGL(k_prep_sphere, leaf_grid, dim3(BLOCK), 0, stream, tri, h.k_of, h.n, d.origin_bound, leaf_sphere);
-        else if (prim == 1) hipLaunchKernelGGL(k_prep_ell_sphere, leaf_grid, dim3(BLOCK), 0, stream, ell, h.k_of, h.n, d.origin_bound, leaf_sphere);
-        else hipLaunchKernelGGL(k_prep_sph_sphere, leaf_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(sph), h.k_of, h.n, d.origin_bound, leaf_sphere);
-        hipLaunchKernelGGL(k_prep_cluster_sphere, cl_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(leaf_sphere), h.n, h.n_clusters, d.origin_bound, cl_sphere);
-        hipLaunchKernelGGL(k_prep_cluster_sphere, top_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(cl_sphere), h.n_clusters, h.n_tops, d.origin_bound, top_sphere);
-        for (size_t l = 0; l < n_pl; ++l) {
-            const float* L = desc->point_light_sources + l * 6;
-            float4* leaf = leaf_light + l * h.n;
-            if (prim == 0) hipLaunchKernelGGL(k_prep_cone, leaf_grid, dim3(BLOCK), 0, stream, tri, h.k_of, h.n, L[0], L[1], L[2], d.origin_bound, 1, leaf);
-            else if (prim == 1) hipLaunchKernelGGL(k_prep_ell_cone, leaf_grid, dim3(BLOCK), 0, stream, ell, h.k_of, h.n, L[0], L[1], L[2], d.origin_bound, 1, leaf);
-            else hipLaunchKernelGGL(k_prep_sph_cone, leaf_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(sph), h.k_of, h.n, L[0], L[1], L[2], d.origin_bound, 1, leaf);
-            hipLaunchKernelGGL(k_prep_cluster_cone, cl_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(leaf), h.n, h.n_clusters, cl_light + l * h.n_clusters);
-            hipLaunchKernelGGL(k_prep_cluster_cone, top_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(cl_light + l * h.n_clusters), h.n_clusters, h.n_tops, top_light + l * h.n_tops);
         }
     }
 
