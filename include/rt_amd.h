@@ -123,10 +123,10 @@ typedef struct rt_stats {
     double   shadow_ms;           /* HIP-event time summed over the shadow scan launches */
     uint64_t closest_launches;    /* launches timed in closest_ms */
     uint64_t shadow_launches;     /* launches timed in shadow_ms */
-    uint64_t full_tests;          /* ray-triangle tests that went through the full test after the pre-test (0 with RT_FLAG_NO_FILTER) */
-    uint64_t pair_pretests[2];    /* ray-triangle pairs the per-wave (packet) pre-test left to the per-ray pre-test: closest-hit scans, shadow scans (0 with RT_FLAG_NO_FILTER) */
-    uint64_t queued_pairs[2];     /* of which the per-ray pre-test kept (queued for the two-stage pre-test and the full test): closest-hit scans, shadow scans */
-    uint64_t executed_flop[2];    /* FLOP the hierarchy scans executed in per-ray tests (child records 6 cone / 18 sphere, two-stage pre-test 40, full test 54 triangle / 95 or 71 ellipsoid): closest-hit scans, shadow scans; per-wave packet tests and top-level tests not counted */
+    uint64_t full_tests;          /* ray-triangle pairs that went through the full test after the two-stage pre-test (hierarchy scans only) */
+    uint64_t pair_pretests[2];    /* per-ray box tests of the hierarchy scans (top nodes the per-wave test kept, and children of kept nodes): closest-hit scans, shadow scans */
+    uint64_t queued_pairs[2];     /* (ray, primitive) pairs the boxes left over, i.e. sent to the two-stage pre-test (triangles) or the full test: closest-hit scans, shadow scans */
+    uint64_t executed_flop[2];    /* FLOP the hierarchy scans executed in per-ray tests (box test 24, two-stage pre-test 40, full test 54 triangle / 19 sphere / 95 or 71 ellipsoid): closest-hit scans, shadow scans */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;          /* opaque: device-resident scene */

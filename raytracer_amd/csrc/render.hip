@@ -1149,6 +1149,9 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
         packet = uniform_packet(packet);
     }
     const bool keep_all = __any(unsafe);
+    uint32_t wave_rays = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) wave_rays += __popcll(__ballot(valid[r]));
 
     // (ray, leaf) pairs: the full test of the kind (triangles: after the two-stage pre-test), one pair per lane
     auto drain2 = [&]() {
@@ -1248,6 +1251,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             mask &= mask - 1ull;
             const float4 lo = readlane4(mine_lo, bit), hi = readlane4(mine_hi, bit);
             uint32_t keep_bits = 0;
+            n_pairs += wave_rays;   // the per-ray tests of this top node
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 keep_bits |= ((GROWN ? box_keeps_grown(box_ray[r], lo, hi, grow[r]) : box_keeps(box_ray[r], lo, hi)) || keep_all) && valid[r] ? 1u << r : 0u;
@@ -1715,6 +1719,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
                 mask &= mask - 1ull;
                 const float4 lo = readlane4(mine_lo, bit), hi = readlane4(mine_hi, bit);
                 uint32_t keep_bits = 0;
+                n_pairs += live;   // the per-ray tests of this top node
 #pragma unroll
                 for (int r = 0; r < R; ++r) keep_bits |= (box_keeps(box_ray[r], lo, hi) || keep_all) && valid[r] && !blocked[r] ? 1u << r : 0u;
                 if (__any(keep_bits != 0u)) {
@@ -2109,7 +2114,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     if (chunk_tiles > 65536) chunk_tiles = 65536;
     if (chunk_tiles > my_tiles) chunk_tiles = my_tiles ? my_tiles : 1;
     // unless the caller fixed the chunk size, a frame that would be one chunk is cut into one chunk per lane
-    if (prm->chunk_tiles == 0 && my_tiles <= chunk_tiles && my_tiles >= 2 * MIN_LANE_TILES) chunk_tiles = ceil_div(my_tiles, std::min(MAX_LANES, my_tiles / MIN_LANE_TILES));
+    // (not in brute-force mode, whose launches are timed one by one)
+    if (prm->chunk_tiles == 0 && (prm->flags & RT_FLAG_NO_FILTER) == 0 && my_tiles <= chunk_tiles && my_tiles >= 2 * MIN_LANE_TILES) chunk_tiles = ceil_div(my_tiles, std::min(MAX_LANES, my_tiles / MIN_LANE_TILES));
     const size_t chunk_samples = static_cast<size_t>(chunk_tiles) * SAMPLES_PER_TILE;
     const uint32_t n_lanes = std::min(MAX_LANES, ceil_div(my_tiles, chunk_tiles));
     for (uint32_t l = 0; l < n_lanes; ++l) if (int rc = ensure_state(g_lib.lanes[l], chunk_samples)) return rc;
