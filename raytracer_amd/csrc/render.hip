@@ -83,15 +83,16 @@ constexpr uint32_t SAMPLES_PER_TILE = RT_TILE * RT_TILE * RT_SAMPLES_PER_PIXEL; 
 
 // Bounding records of one primitive kind (triangles, ellipsoids or spheres) for the conservative
 // pre-test of the scans: axis-aligned boxes, 2 x float4 per node, (lo, 0) (hi, 0), see box_keeps.
-// Three levels: leaves (one per primitive), clusters (CLUSTER consecutive leaves) and top nodes
-// (CLUSTER consecutive clusters); the box of a cluster or top node contains the boxes of everything
-// below it.  Leaves are stored in CLUSTER ORDER: position s holds the primitive with scan index
+// Four levels: leaves (one per primitive), clusters (CLUSTER consecutive leaves), top nodes
+// (CLUSTER consecutive clusters) and super nodes (CLUSTER consecutive top nodes); the box of a node
+// contains the boxes of everything below it.  A scan starts at the top nodes, or at the super
+// nodes when the top level is long (LEVELS of the scan kernels).  Leaves are stored in CLUSTER ORDER: position s holds the primitive with scan index
 // k_of[s], and consecutive positions are neighbours in space (leaf order of a kd tree, built by
 // the host at scene creation).  One hierarchy serves every ray: from the eye, reflected, shadow.
 struct Hierarchy {
     const uint32_t* k_of;
-    const float4 *leaf_box, *cl_box, *top_box;
-    uint32_t n, n_clusters, n_tops;
+    const float4 *leaf_box, *cl_box, *top_box, *super_box;
+    uint32_t n, n_clusters, n_tops, n_supers;
 };
 
 struct DevScene {
@@ -965,8 +966,8 @@ DEV void load_rays(const State& st, const uint32_t* __restrict__ list_in, uint32
 // atomicMin / atomicOr.  S is derived from the ray count alone, so every workgroup agrees on it.
 constexpr uint32_t SEG_TARGET = 4096;   // workgroups a small launch is spread over
 struct ScanSplit { uint32_t ray_base, first_prim, end_prim; bool active; };
-DEV ScanSplit scan_split(uint32_t n_rays, uint32_t rays_per_block, uint32_t n_prims) {
-    constexpr uint32_t STEP = 16;   // granule of a segment, in top nodes (the scan walks 64 at a time, one per lane; a short segment leaves lanes idle there, which is cheap)
+// STEP: granule of a segment, in nodes of the level the scan starts at (it walks 64 at a time, one per lane; a short segment leaves lanes idle there, which is cheap)
+DEV ScanSplit scan_split(uint32_t n_rays, uint32_t rays_per_block, uint32_t n_prims, uint32_t STEP) {
     ScanSplit sp{0, 0, 0, false};
     const uint32_t n_blocks = (n_rays + rays_per_block - 1) / rays_per_block;
     if (n_blocks == 0) return sp;
@@ -1054,14 +1055,17 @@ DEV float pretests_then_full(const DevScene& sc, const TriPair& f, V3 o, V3 d, u
 // three per-wave queues in LDS (top node -> cluster -> leaf), each walked one pair per lane, and
 // the (ray, leaf) pairs that remain through the full test of the kind (for triangles after the
 // two-stage pre-test).  Result: st.key[slot] / st.key_ell[slot] / st.key_sph[slot], by atomicMin.
-template <int R, bool WALK, int PRIM>
+template <int R, int LEVELS, int PRIM>
 __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc, State st, uint32_t bounce) {
+    static_assert(LEVELS == 0 || LEVELS == 3 || LEVELS == 4, "brute force, or a walk from the top nodes or from the super nodes");
+    constexpr bool WALK = LEVELS != 0;
+    constexpr int N_QUEUES = WALK ? LEVELS : 3;
     static_assert(WALK || PRIM == 0, "the full-test mode of this kernel is for triangles");
     static_assert(64 * R <= PUSH_MAX && 64 * R <= 256, "a queue entry has 8 bits for the ray, a push adds at most PUSH_MAX entries");
     const Hierarchy& h = PRIM == 0 ? sc.th : (PRIM == 1 ? sc.eh : sc.sh);
     constexpr int WORDS = 4;
     __shared__ float4 lds[WALK ? 1 : TILE_PRIMS * WORDS];   // record tiles, full-test mode only
-    constexpr uint32_t WAVE_LDS = 3 * QCAP + 64 * R;   // per wave: (ray, top node), (ray, cluster) and (ray, leaf) queues, slot table
+    constexpr uint32_t WAVE_LDS = N_QUEUES * QCAP + 64 * R;   // per wave: one queue per level ((ray, top node), (ray, cluster), (ray, leaf), with LEVELS = 4 also (ray, super node)), slot table
     __shared__ uint32_t lds_queue[WALK ? (BLOCK / 64) * WAVE_LDS : 1];
     const uint32_t n_rays = st.counts[bounce];
     const uint32_t* __restrict__ list_in = st.list[bounce & 1u];
@@ -1069,7 +1073,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     if (!WALK) {
         split = ScanSplit{blockIdx.x * (BLOCK * R), 0u, sc.n_tri, blockIdx.x * (BLOCK * R) < n_rays};
     } else {
-        split = scan_split(n_rays, BLOCK * R, h.n_tops);
+        split = scan_split(n_rays, BLOCK * R, LEVELS == 4 ? h.n_supers : h.n_tops, LEVELS == 4 ? 1u : 16u);
     }
     if (!split.active) return;
     const uint32_t base = split.ray_base;
@@ -1112,8 +1116,9 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     uint32_t* const q0 = lds_queue + wave * WAVE_LDS;      // (ray, top node)
     uint32_t* const q1 = q0 + QCAP;                        // (ray, cluster)
     uint32_t* const q2 = q1 + QCAP;                        // (ray, leaf)
-    uint32_t* const wave_slots = q2 + QCAP;                // slot of ray r*64 + lane
-    uint32_t q0_count = 0, q1_count = 0, q2_count = 0, n_full = 0, n_queued = 0;
+    uint32_t* const qs = q2 + QCAP;                        // (ray, super node), LEVELS = 4 only
+    uint32_t* const wave_slots = q0 + N_QUEUES * QCAP;     // slot of ray r*64 + lane
+    uint32_t q0_count = 0, q1_count = 0, q2_count = 0, qs_count = 0, n_full = 0, n_queued = 0;
     unsigned long long n_pairs = 0;
 
     // a wave owns 64*R consecutive rays of the list, so that its packet bound is as narrow as the list allows
@@ -1154,7 +1159,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     for (int r = 0; r < R; ++r) wave_rays += __popcll(__ballot(valid[r]));
 
     // (ray, leaf) pairs: the full test of the kind (triangles: after the two-stage pre-test), one pair per lane
-    auto drain2 = [&]() {
+    auto drain2 = [&]() __attribute__((always_inline)) {
         wave_sync();
         if (PRIM == 0) {
             for (uint32_t i = lane; i < q2_count; i += 64) {
@@ -1197,7 +1202,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     // (ray, node) pairs: one pair per lane, the lane walks the CLUSTER children of its node and queues
     // the ones its ray may reach one level down
     auto walk = [&](uint32_t* q_in, uint32_t& in_count, const float4* __restrict__ child, uint32_t n_child,
-                    uint32_t* q_out, uint32_t& out_count, auto&& drain_out) {
+                    uint32_t* q_out, uint32_t& out_count, auto&& drain_out) __attribute__((always_inline)) {
         wave_sync();
         for (uint32_t i0 = 0; i0 < in_count; i0 += 64) {
             const bool active = i0 + lane < in_count;
@@ -1237,13 +1242,19 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
         wave_sync();
         in_count = 0;
     };
-    auto drain1 = [&]() { walk(q1, q1_count, h.leaf_box, h.n, q2, q2_count, drain2); };
-    auto drain0 = [&]() { walk(q0, q0_count, h.cl_box, h.n_clusters, q1, q1_count, drain1); };
+    auto drain1 = [&]() __attribute__((always_inline)) { walk(q1, q1_count, h.leaf_box, h.n, q2, q2_count, drain2); };
+    auto drain0 = [&]() __attribute__((always_inline)) { walk(q0, q0_count, h.cl_box, h.n_clusters, q1, q1_count, drain1); };
+    auto drain_supers = [&]() __attribute__((always_inline)) { walk(qs, qs_count, h.top_box, h.n_tops, q0, q0_count, drain0); };
+    // the level the scan starts at: its boxes are tested one per lane against the wave's bound, then per ray
+    const float4* __restrict__ first_box = LEVELS == 4 ? h.super_box : h.top_box;
+    uint32_t* const q_first = LEVELS == 4 ? qs : q0;
+    uint32_t& first_count = LEVELS == 4 ? qs_count : q0_count;
+    auto drain_first = [&]() __attribute__((always_inline)) { if constexpr (LEVELS == 4) drain_supers(); else drain0(); };
 
     wave_sync();
     for (uint32_t c0 = split.first_prim; c0 < split.end_prim; c0 += 64) {
         const size_t mine_at = min(c0 + lane, split.end_prim - 1u);
-        const float4 mine_lo = h.top_box[mine_at * 2], mine_hi = h.top_box[mine_at * 2 + 1];
+        const float4 mine_lo = first_box[mine_at * 2], mine_hi = first_box[mine_at * 2 + 1];
         const bool reach = packet_sphere_keeps(packet, box_sphere(mine_lo, mine_hi));
         unsigned long long mask = __ballot((reach || keep_all) && c0 + lane < split.end_prim);
         while (mask) {
@@ -1256,12 +1267,13 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             for (int r = 0; r < R; ++r)
                 keep_bits |= ((GROWN ? box_keeps_grown(box_ray[r], lo, hi, grow[r]) : box_keeps(box_ray[r], lo, hi)) || keep_all) && valid[r] ? 1u << r : 0u;
             if (__any(keep_bits != 0u)) {
-                if (q0_count + PUSH_MAX > QCAP) drain0();
-                push_bits(q0, q0_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
+                if (first_count + PUSH_MAX > QCAP) drain_first();
+                push_bits(q_first, first_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
             }
         }
     }
-    drain0();
+    drain_first();
+    if constexpr (LEVELS == 4) drain0();
     drain1();
     drain2();
     if (PRIM == 0) block_add_stat(stat_slot(st, ST_FULL_TESTS), n_full);
@@ -1514,14 +1526,17 @@ DEV ShadowRay make_shadow_ray(const State& st, uint32_t slot, bool point, V3 lv)
 // WALK = false: brute force over the triangles.  WALK = true: the box hierarchy of the kind, queues
 // as in k_closest_scan; a (ray, leaf) pair that blocks sets the ray's bit in LDS, which the lane
 // that holds the ray picks up after the drain; the wave stops when all its rays are blocked.
-template <int R, bool WALK, int PRIM>
+template <int R, int LEVELS, int PRIM>
 __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
+    static_assert(LEVELS == 0 || LEVELS == 3 || LEVELS == 4, "brute force, or a walk from the top nodes or from the super nodes");
+    constexpr bool WALK = LEVELS != 0;
+    constexpr int N_QUEUES = WALK ? LEVELS : 3;
     static_assert(WALK || PRIM == 0, "the full-test mode of this kernel is for triangles");
     static_assert(64 * R <= PUSH_MAX && 64 * R <= 256, "a queue entry has 8 bits for the ray, a push adds at most PUSH_MAX entries");
     const Hierarchy& h = PRIM == 0 ? sc.th : (PRIM == 1 ? sc.eh : sc.sh);
     constexpr int WORDS = 4;
     __shared__ float4 lds[WALK ? 1 : TILE_PRIMS * WORDS];   // record tiles, full-test mode only
-    constexpr uint32_t WAVE_LDS = 3 * QCAP + 64 * R;   // per wave: (ray, top node), (ray, cluster) and (ray, leaf) queues, slot table
+    constexpr uint32_t WAVE_LDS = N_QUEUES * QCAP + 64 * R;   // per wave: one queue per level ((ray, top node), (ray, cluster), (ray, leaf), with LEVELS = 4 also (ray, super node)), slot table
     __shared__ uint32_t lds_queue[WALK ? (BLOCK / 64) * WAVE_LDS : 1];
     __shared__ uint32_t lds_blocked[BLOCK];   // bit r: ray r of that thread is blocked (set by drains)
     const uint32_t n_rays = st.counts[bounce + 1];
@@ -1529,7 +1544,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     if (!WALK) {
         split = ScanSplit{blockIdx.x * (BLOCK * R), 0u, sc.n_tri, blockIdx.x * (BLOCK * R) < n_rays};
     } else {
-        split = scan_split(n_rays, BLOCK * R, h.n_tops);
+        split = scan_split(n_rays, BLOCK * R, LEVELS == 4 ? h.n_supers : h.n_tops, LEVELS == 4 ? 1u : 16u);
     }
     if (!split.active) return;
     const uint32_t base = split.ray_base;
@@ -1564,7 +1579,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             unsafe |= !(fmaxf(fabsf(s.o.x), fmaxf(fabsf(s.o.y), fabsf(s.o.z))) <= sc.box_bound);
             if (!point) unsafe |= !(vdot(s.d, s.d) <= SPH_DIR_CHECK);   // a directional light's direction is the caller's: the pre-tests and the spheres' boxes need unit length
             blocked[r] = (st.blocked[slot[r]] & light_bit) != 0u;
-            if (WALK) lds_queue[(threadIdx.x >> 6) * WAVE_LDS + 3 * QCAP + r * 64 + (threadIdx.x & 63u)] = slot[r];
+            if (WALK) lds_queue[(threadIdx.x >> 6) * WAVE_LDS + N_QUEUES * QCAP + r * 64 + (threadIdx.x & 63u)] = slot[r];
         }
         if (WALK) packet = uniform_packet(make_packet<R>(d, o, valid));
     }
@@ -1582,15 +1597,16 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     uint32_t* const q0 = lds_queue + wave * WAVE_LDS;      // (ray, top node)
     uint32_t* const q1 = q0 + QCAP;                        // (ray, cluster)
     uint32_t* const q2 = q1 + QCAP;                        // (ray, leaf)
-    uint32_t* const wave_slots = q2 + QCAP;                // slot of ray r*64 + lane
-    uint32_t q0_count = 0, q1_count = 0, q2_count = 0, n_full = 0, n_queued = 0;
+    uint32_t* const qs = q2 + QCAP;                        // (ray, super node), LEVELS = 4 only
+    uint32_t* const wave_slots = q0 + N_QUEUES * QCAP;     // slot of ray r*64 + lane
+    uint32_t q0_count = 0, q1_count = 0, q2_count = 0, qs_count = 0, n_full = 0, n_queued = 0;
     unsigned long long n_pairs = 0;
     // blocked bits of the wave's rays live in lds_blocked[thread that holds the ray], bit r; ray = r*64 + lane
     auto ray_blocked = [&](uint32_t ray) {
         return ((__hip_atomic_load(&lds_blocked[wave * 64u + (ray & 63u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> (ray >> 6)) & 1u) != 0u;
     };
     // (ray, leaf) pairs: the full test of the kind (triangles: after the two-stage pre-test), one pair per lane; a pair that blocks sets its ray's bit
-    auto drain2 = [&]() {
+    auto drain2 = [&]() __attribute__((always_inline)) {
         wave_sync();
         if (PRIM == 0) {
             for (uint32_t i = lane; i < q2_count; i += 64) {
@@ -1630,7 +1646,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     // (ray, node) pairs: one pair per lane, the lane walks the CLUSTER children of its node and queues
     // the ones its ray may reach one level down; pairs of rays that are blocked by now are dropped
     auto walk = [&](uint32_t* q_in, uint32_t& in_count, const float4* __restrict__ child, uint32_t n_child,
-                    uint32_t* q_out, uint32_t& out_count, auto&& drain_out) {
+                    uint32_t* q_out, uint32_t& out_count, auto&& drain_out) __attribute__((always_inline)) {
         wave_sync();
         for (uint32_t i0 = 0; i0 < in_count; i0 += 64) {
             bool active = i0 + lane < in_count;
@@ -1669,8 +1685,14 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
         wave_sync();
         in_count = 0;
     };
-    auto drain1 = [&]() { walk(q1, q1_count, h.leaf_box, h.n, q2, q2_count, drain2); };
-    auto drain0 = [&]() { walk(q0, q0_count, h.cl_box, h.n_clusters, q1, q1_count, drain1); };
+    auto drain1 = [&]() __attribute__((always_inline)) { walk(q1, q1_count, h.leaf_box, h.n, q2, q2_count, drain2); };
+    auto drain0 = [&]() __attribute__((always_inline)) { walk(q0, q0_count, h.cl_box, h.n_clusters, q1, q1_count, drain1); };
+    auto drain_supers = [&]() __attribute__((always_inline)) { walk(qs, qs_count, h.top_box, h.n_tops, q0, q0_count, drain0); };
+    // the level the scan starts at: its boxes are tested one per lane against the wave's bound, then per ray
+    const float4* __restrict__ first_box = LEVELS == 4 ? h.super_box : h.top_box;
+    uint32_t* const q_first = LEVELS == 4 ? qs : q0;
+    uint32_t& first_count = LEVELS == 4 ? qs_count : q0_count;
+    auto drain_first = [&]() __attribute__((always_inline)) { if constexpr (LEVELS == 4) drain_supers(); else drain0(); };
 
     unsigned long long wave_tests = 0;   // tests spent on still-undecided rays (wave-uniform)
     bool done = wave_done();
@@ -1710,8 +1732,9 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
         uint32_t live = live_rays(), steps = 0;
         for (uint32_t c0 = split.first_prim; c0 < split.end_prim && live != 0; c0 += 64) {
             const size_t mine_at = min(c0 + lane, split.end_prim - 1u);
-            const float4 mine_lo = h.top_box[mine_at * 2], mine_hi = h.top_box[mine_at * 2 + 1];
-            wave_tests += static_cast<unsigned long long>(min(h.n, min(c0 + 64u, split.end_prim) * (CLUSTER * CLUSTER)) - c0 * (CLUSTER * CLUSTER)) * live;
+            const float4 mine_lo = first_box[mine_at * 2], mine_hi = first_box[mine_at * 2 + 1];
+            constexpr uint32_t NODE_PRIMS = LEVELS == 4 ? CLUSTER * CLUSTER * CLUSTER : CLUSTER * CLUSTER;   // primitives below a node of the first level
+            wave_tests += static_cast<unsigned long long>(min(h.n, min(c0 + 64u, split.end_prim) * NODE_PRIMS) - c0 * NODE_PRIMS) * live;
             const bool reach = packet_sphere_keeps(packet, box_sphere(mine_lo, mine_hi));
             unsigned long long mask = __ballot((reach || keep_all) && c0 + lane < split.end_prim);
             while (mask) {
@@ -1723,12 +1746,12 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
 #pragma unroll
                 for (int r = 0; r < R; ++r) keep_bits |= (box_keeps(box_ray[r], lo, hi) || keep_all) && valid[r] && !blocked[r] ? 1u << r : 0u;
                 if (__any(keep_bits != 0u)) {
-                    if (q0_count + PUSH_MAX > QCAP) drain0();
-                    push_bits(q0, q0_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
+                    if (first_count + PUSH_MAX > QCAP) drain_first();
+                    push_bits(q_first, first_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
                 }
             }
             // work the queues off before looking at "all blocked"; the last step does it for the whole scan
-            if (++steps % SHADOW_CHECK_STEPS == 0 || c0 + 64 >= split.end_prim) { drain0(); drain1(); drain2(); live = live_rays(); }
+            if (++steps % SHADOW_CHECK_STEPS == 0 || c0 + 64 >= split.end_prim) { drain_first(); if constexpr (LEVELS == 4) drain0(); drain1(); drain2(); live = live_rays(); }
         }
     }
 #pragma unroll
@@ -1953,8 +1976,9 @@ constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;   // brute-force scans
 // Rays per lane of the hierarchy scans.  A wave's life is a chain of dependent L2 round trips whose
 // length grows with its number of rays, and a launch ends with its slowest wave: one ray per lane
 // is best while the top level is short (scene7: 391 top nodes).  Walking a long top level once per
-// wave costs more than that, so big scenes (the synthetic one: 3907 top nodes) take two.
-constexpr uint32_t TOPS_FOR_TWO_RAYS = 1024;
+// wave costs more than that, so big scenes (the synthetic one: 3907 top nodes) take two, and start
+// the walk one level higher, at the super nodes (synthetic scene: 593 -> 561 ms; scene7 would lose: 25 -> 30 ms).
+constexpr uint32_t TOPS_FOR_DEEP_WALK = 1024;
 // A kind with at most this many slots is scanned by brute force even in the default mode: the walk of
 // a hierarchy costs more than it saves there (measured crossover: 32 to 64 slots for every kind;
 // scene6, 40 + 8 + 8 slots and 1.15 G rays at 3840x2160: 208 ms walking, 141 ms brute force).
@@ -2077,26 +2101,30 @@ void build_boxes(const rt_scene* scene, float bound, hipStream_t stream) {
         float4* leaf = const_cast<float4*>(h.leaf_box);
         float4* cl = const_cast<float4*>(h.cl_box);
         float4* top = const_cast<float4*>(h.top_box);
-        const dim3 leaf_grid(ceil_div(h.n, BLOCK)), cl_grid(ceil_div(h.n_clusters, BLOCK)), top_grid(ceil_div(h.n_tops, BLOCK));
+        float4* super = const_cast<float4*>(h.super_box);
+        const dim3 leaf_grid(ceil_div(h.n, BLOCK)), cl_grid(ceil_div(h.n_clusters, BLOCK)), top_grid(ceil_div(h.n_tops, BLOCK)), super_grid(ceil_div(h.n_supers, BLOCK));
         if (prim == 0) hipLaunchKernelGGL(k_prep_tri_box, leaf_grid, dim3(BLOCK), 0, stream, sc.tri, h.k_of, h.n, bound, leaf);
         else if (prim == 1) hipLaunchKernelGGL(k_prep_ell_box, leaf_grid, dim3(BLOCK), 0, stream, sc.ell, h.k_of, h.n, bound, leaf);
         else hipLaunchKernelGGL(k_prep_sph_box, leaf_grid, dim3(BLOCK), 0, stream, sc.sph, h.k_of, h.n, bound, leaf);
         hipLaunchKernelGGL(k_prep_cluster_box, cl_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(leaf), h.n, h.n_clusters, cl);
         hipLaunchKernelGGL(k_prep_cluster_box, top_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(cl), h.n_clusters, h.n_tops, top);
+        hipLaunchKernelGGL(k_prep_cluster_box, super_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(top), h.n_tops, h.n_supers, super);
     }
     scene->box_bound = bound;
 }
 const Hierarchy& hierarchy_of(const DevScene& sc, int prim) { return prim == 0 ? sc.th : (prim == 1 ? sc.eh : sc.sh); }
 // box-hierarchy scans of one kind, one or two rays per lane
+// box-hierarchy scans of one kind.  `deep` (more than TOPS_FOR_DEEP_WALK top nodes): two rays per lane and the walk
+// starts at the super nodes; otherwise one ray per lane from the top nodes.
 template <int PRIM>
-void launch_closest_scan(bool two, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b) {
-    if (two) hipLaunchKernelGGL((k_closest_scan<2, true, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b);
-    else hipLaunchKernelGGL((k_closest_scan<1, true, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b);
+void launch_closest_scan(bool deep, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b) {
+    if (deep) hipLaunchKernelGGL((k_closest_scan<2, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b);
+    else hipLaunchKernelGGL((k_closest_scan<1, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b);
 }
 template <int PRIM>
-void launch_shadow_scan(bool two, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b, uint32_t first_light, uint32_t group_first) {
-    if (two) hipLaunchKernelGGL((k_shadow_scan<2, true, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first);
-    else hipLaunchKernelGGL((k_shadow_scan<1, true, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first);
+void launch_shadow_scan(bool deep, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b, uint32_t first_light, uint32_t group_first) {
+    if (deep) hipLaunchKernelGGL((k_shadow_scan<2, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first);
+    else hipLaunchKernelGGL((k_shadow_scan<1, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first);
 }
 
 int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_render_params* prm, uint8_t* tiles_dev,
@@ -2156,6 +2184,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     const bool filter = (prm->flags & RT_FLAG_NO_FILTER) == 0;
     // per kind (0 triangles, 1 ellipsoids, 2 spheres): walk its hierarchy, or scan it by brute force
     const uint32_t below = (prm->flags & RT_FLAG_WALK_ALL) ? 0u : brute_force_below();
+    const bool force_deep = (prm->flags & RT_FLAG_DEEP_WALK) != 0;
     const bool walk[3] = {filter && sc.th.n > below, filter && sc.eh.n > below, filter && sc.sh.n > below};
     if (n_lanes > 1) {   // the other lanes start when the box records and the cleared counters are ready
         HIP_TRY(hipEventRecord(g_lib.lanes_fork, g_lib.lanes[0].stream));
@@ -2192,16 +2221,16 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         // closest-hit scans of bounce b, all kinds, on stream `on`
         auto closest_scans = [&](uint32_t b, hipStream_t on) {
             const State sb = state_of(b);
-            auto hierarchy_scan = [&](int prim) {   // one or two rays per lane (TOPS_FOR_TWO_RAYS)
-                const bool two = hierarchy_of(sc, prim).n_tops > TOPS_FOR_TWO_RAYS;
-                const dim3 grid(blocks_for(two ? 2 : 1));
-                if (prim == 0) launch_closest_scan<0>(two, grid, on, sc, sb, b);
-                else if (prim == 1) launch_closest_scan<1>(two, grid, on, sc, sb, b);
-                else launch_closest_scan<2>(two, grid, on, sc, sb, b);
+            auto hierarchy_scan = [&](int prim) {   // one or two rays per lane, three or four levels (TOPS_FOR_DEEP_WALK)
+                const bool deep = force_deep || hierarchy_of(sc, prim).n_tops > TOPS_FOR_DEEP_WALK;
+                const dim3 grid(blocks_for(deep ? 2 : 1));
+                if (prim == 0) launch_closest_scan<0>(deep, grid, on, sc, sb, b);
+                else if (prim == 1) launch_closest_scan<1>(deep, grid, on, sc, sb, b);
+                else launch_closest_scan<2>(deep, grid, on, sc, sb, b);
             };
             timed(timer, 0, on, [&] {
                 if (sc.n_tri) {
-                    if (!walk[0]) hipLaunchKernelGGL((k_closest_scan<RAYS_PER_LANE, false, 0>), dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
+                    if (!walk[0]) hipLaunchKernelGGL((k_closest_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
                     else hierarchy_scan(0);
                 }
                 if (sc.n_sph) {
@@ -2216,11 +2245,11 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         };
         // box-hierarchy shadow scan of one kind toward the n lights first_light..
         auto shadow_scan = [&](const State& sb, int prim, uint32_t n, uint32_t b, uint32_t first_light, uint32_t group_first) {
-            const bool two = hierarchy_of(sc, prim).n_tops > TOPS_FOR_TWO_RAYS;
-            const dim3 grid(blocks_for(two ? 2 : 1), n);
-            if (prim == 0) launch_shadow_scan<0>(two, grid, stream, sc, sb, b, first_light, group_first);
-            else if (prim == 1) launch_shadow_scan<1>(two, grid, stream, sc, sb, b, first_light, group_first);
-            else launch_shadow_scan<2>(two, grid, stream, sc, sb, b, first_light, group_first);
+            const bool deep = force_deep || hierarchy_of(sc, prim).n_tops > TOPS_FOR_DEEP_WALK;
+            const dim3 grid(blocks_for(deep ? 2 : 1), n);
+            if (prim == 0) launch_shadow_scan<0>(deep, grid, stream, sc, sb, b, first_light, group_first);
+            else if (prim == 1) launch_shadow_scan<1>(deep, grid, stream, sc, sb, b, first_light, group_first);
+            else launch_shadow_scan<2>(deep, grid, stream, sc, sb, b, first_light, group_first);
         };
 
         // Per bounce: closest-hit scans -> k_hit (which also writes the reflected ray) -> list compaction ->
@@ -2255,7 +2284,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                     // brute-force shadow scan of one kind toward lights first.. (n of them)
                     auto brute_force = [&](int prim, uint32_t n, uint32_t first_light) {
                         const dim3 grid(scan_blocks, n);
-                        if (prim == 0) hipLaunchKernelGGL((k_shadow_scan<RAYS_PER_LANE, false, 0>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
+                        if (prim == 0) hipLaunchKernelGGL((k_shadow_scan<RAYS_PER_LANE, 0, 0>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                         else if (prim == 1) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                         else hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                     };
@@ -2525,6 +2554,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
         h.n = prim == 0 ? d.n_tri : (prim == 1 ? d.n_ell : d.n_sph);
         h.n_clusters = ceil_div(h.n, CLUSTER);
         h.n_tops = ceil_div(h.n_clusters, CLUSTER);
+        h.n_supers = ceil_div(h.n_tops, CLUSTER);
         if (h.n == 0) continue;
         std::vector<float> centroid;
         std::vector<uint8_t> good;
@@ -2540,13 +2570,14 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
         }
         orders[prim] = cluster_order(centroid, good);
         uint32_t* k_of;
-        float4 *leaf_box, *cl_box, *top_box;
+        float4 *leaf_box, *cl_box, *top_box, *super_box;
         if ((rc = upload(s, orders[prim].data(), orders[prim].size(), &k_of))) return fail(rc);
         if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n) * 2, &leaf_box))) return fail(rc);
         if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n_clusters) * 2, &cl_box))) return fail(rc);
         if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n_tops) * 2, &top_box))) return fail(rc);
+        if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n_supers) * 2, &super_box))) return fail(rc);
         h.k_of = k_of;
-        h.leaf_box = leaf_box; h.cl_box = cl_box; h.top_box = top_box;
+        h.leaf_box = leaf_box; h.cl_box = cl_box; h.top_box = top_box; h.super_box = super_box;
         if (prim == 0) {
             float4* trif_pos;
             if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n) * 4, &trif_pos))) return fail(rc);

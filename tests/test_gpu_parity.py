@@ -40,12 +40,14 @@ def _render_both(gpu, oracle, name, rect, **overrides):
     return g, o
 
 
-@pytest.mark.parametrize("walk_all", [False, True], ids=["default", "walk_all"])
+@pytest.mark.parametrize("mode", ["default", "walk_all", "deep_walk"])
 @pytest.mark.parametrize("name,rect", CASES, ids=[c[0] for c in CASES])
-def test_image_and_ids_match_oracle(gpu, oracle, name, rect, walk_all):
-    # default: kinds of at most 64 slots are scanned by brute force; walk_all: every kind through its bounding hierarchy
+def test_image_and_ids_match_oracle(gpu, oracle, name, rect, mode):
+    # default: kinds of at most 64 slots are scanned by brute force; walk_all: every kind through its box hierarchy;
+    # deep_walk: likewise, walked the way big scenes are (from the super nodes, two rays per lane)
     from raytracer_amd import abi
-    g, o = _render_both(gpu, oracle, name, rect, flags=abi.RT_FLAG_WALK_ALL if walk_all else 0)
+    flags = {"default": 0, "walk_all": abi.RT_FLAG_WALK_ALL, "deep_walk": abi.RT_FLAG_WALK_ALL | abi.RT_FLAG_DEEP_WALK}[mode]
+    g, o = _render_both(gpu, oracle, name, rect, flags=flags)
     id_diff = int((g["ids"] != o["ids"]).sum())
     px_diff = int((g["rgb"] != o["rgb"]).any(axis=2).sum())
     max_lsb = int(np.abs(g["rgb"].astype(int) - o["rgb"].astype(int)).max())

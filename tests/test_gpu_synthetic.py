@@ -39,10 +39,12 @@ def test_pretests_are_invisible_and_match_oracle(gpu, oracle, tmp_path, kw):
     a = scene.render(cam, fi.params(flags=abi.RT_FLAG_WALK_ALL), want_ids=True)     # every kind through its hierarchy
     b = scene.render(cam, fi.params(flags=abi.RT_FLAG_NO_FILTER), want_ids=True)
     c = scene.render(cam, fi.params(), want_ids=True)                                # small kinds by brute force
-    assert np.array_equal(a["ids"], b["ids"]) and np.array_equal(c["ids"], b["ids"])
-    assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(c["rgb"], b["rgb"])
-    for f in ("closest_rays", "hits", "shadow_rays", "shadow_blocked"):
-        assert getattr(a["stats"], f) == getattr(b["stats"], f), f
+    d = scene.render(cam, fi.params(flags=abi.RT_FLAG_WALK_ALL | abi.RT_FLAG_DEEP_WALK), want_ids=True)   # the walk of big scenes: four levels, two rays per lane
+    for other in (a, c, d):
+        assert np.array_equal(other["ids"], b["ids"])
+        assert np.array_equal(other["rgb"], b["rgb"])
+        for f in ("closest_rays", "hits", "shadow_rays", "shadow_blocked"):
+            assert getattr(other["stats"], f) == getattr(b["stats"], f), f
     assert a["stats"].hits > 0 and a["stats"].shadow_blocked > 0
     assert a["stats"].full_tests < 0.02 * (sum(a["stats"].closest_tests) + sum(a["stats"].shadow_tests))
 
