@@ -1225,7 +1225,9 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
                 uint32_t keep_bits = 0;
 #pragma unroll
                 for (int u = 0; u < WALK_BATCH; ++u) {
-                    const bool keep = active && first + t0 + u <= last && ((GROWN ? box_keeps_grown(ray, lo[u], hi[u], gr) : box_keeps(ray, lo[u], hi[u])) || keep_all);
+                    // no short circuit: the test is cheaper than a branch around it
+                    const bool hit = GROWN ? box_keeps_grown(ray, lo[u], hi[u], gr) : box_keeps(ray, lo[u], hi[u]);
+                    const bool keep = (active & (first + t0 + u <= last)) & (hit | keep_all);
                     keep_bits |= keep ? 1u << u : 0u;
                 }
 #pragma nounroll
@@ -1668,7 +1670,9 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
                 uint32_t keep_bits = 0;
 #pragma unroll
                 for (int u = 0; u < WALK_BATCH; ++u) {
-                    const bool keep = active && first + t0 + u <= last && (box_keeps(ray, lo[u], hi[u]) || keep_all);
+                    // no short circuit: the test is cheaper than a branch around it
+                    const bool hit = box_keeps(ray, lo[u], hi[u]);
+                    const bool keep = (active & (first + t0 + u <= last)) & (hit | keep_all);
                     keep_bits |= keep ? 1u << u : 0u;
                 }
 #pragma nounroll
