@@ -964,7 +964,10 @@ DEV void load_rays(const State& st, const uint32_t* __restrict__ list_in, uint32
 // the time of the launch is the time of its busiest wave, so the top-node list is cut into S
 // segments and (ray block, segment) pairs are spread over the grid; results combine through
 // atomicMin / atomicOr.  S is derived from the ray count alone, so every workgroup agrees on it.
-constexpr uint32_t SEG_TARGET = 4096;   // workgroups a small launch is spread over
+#ifndef RT_SEG_TARGET
+#define RT_SEG_TARGET 2048
+#endif
+constexpr uint32_t SEG_TARGET = RT_SEG_TARGET;   // workgroups a small launch is spread over
 struct ScanSplit { uint32_t ray_base, first_prim, end_prim; bool active; };
 // STEP: granule of a segment, in nodes of the level the scan starts at (it walks 64 at a time, one per lane; a short segment leaves lanes idle there, which is cheap)
 DEV ScanSplit scan_split(uint32_t n_rays, uint32_t rays_per_block, uint32_t n_prims, uint32_t STEP) {
