@@ -1013,6 +1013,9 @@ DEV void wave_sync() {
 #define RT_QCAP 384
 #endif
 constexpr uint32_t QCAP = RT_QCAP, PUSH_MAX = 256;
+#ifndef RT_STAGE_RAYS
+#define RT_STAGE_RAYS(R, LEVELS) ((LEVELS) == 3)
+#endif
 #ifndef RT_WALK_BATCH
 #define RT_WALK_BATCH 4
 #endif
@@ -1070,6 +1073,9 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     __shared__ float4 lds[WALK ? 1 : TILE_PRIMS * WORDS];   // record tiles, full-test mode only
     constexpr uint32_t WAVE_LDS = N_QUEUES * QCAP + 64 * R;   // per wave: one queue per level ((ray, top node), (ray, cluster), (ray, leaf), with LEVELS = 4 also (ray, super node)), slot table
     __shared__ uint32_t lds_queue[WALK ? (BLOCK / 64) * WAVE_LDS : 1];
+    // the wave's rays, staged once for the lanes that walk their pairs: (o, growth) (d, -) (1/d, -) per ray
+    constexpr bool STAGED = WALK && RT_STAGE_RAYS(R, LEVELS);
+    __shared__ float4 lds_rays[STAGED ? (BLOCK / 64) * 64 * R * 3 : 1];
     const uint32_t n_rays = st.counts[bounce];
     const uint32_t* __restrict__ list_in = st.list[bounce & 1u];
     ScanSplit split;
@@ -1123,6 +1129,23 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     uint32_t* const wave_slots = q0 + N_QUEUES * QCAP;     // slot of ray r*64 + lane
     uint32_t q0_count = 0, q1_count = 0, q2_count = 0, qs_count = 0, n_full = 0, n_queued = 0;
     unsigned long long n_pairs = 0;
+    float4* const wave_rays_lds = lds_rays + (STAGED ? wave * (64 * R * 3) : 0);
+    // ray number `ray` of the wave (r*64 + lane of its owner) for the lane that handles one of its pairs
+    struct PairRay { V3 o, d, inv; float grow; };
+    auto pair_ray = [&](uint32_t ray) __attribute__((always_inline)) {
+        PairRay p;
+        if (STAGED) {
+            const float4 a = wave_rays_lds[ray * 3], b = wave_rays_lds[ray * 3 + 1], c = wave_rays_lds[ray * 3 + 2];
+            p.o = xyz(a); p.d = xyz(b); p.inv = xyz(c); p.grow = a.w;
+        } else {
+            const uint32_t s = wave_slots[ray];
+            p.o = {st.ox[s], st.oy[s], st.oz[s]};
+            p.d = {st.dx[s], st.dy[s], st.dz[s]};
+            p.inv = make_box_ray(p.o, p.d, FLT_MAX).inv;
+            p.grow = PRIM == 2 ? sphere_growth(p.d, sc.box_bound) : 0.0f;
+        }
+        return p;
+    };
 
     // a wave owns 64*R consecutive rays of the list, so that its packet bound is as narrow as the list allows
     uint32_t slot[R];
@@ -1144,6 +1167,12 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             box_ray[r] = make_box_ray(o[r], d[r], FLT_MAX);
             grow[r] = GROWN ? sphere_growth(d[r], sc.box_bound) : 0.0f;
             unsafe |= !(fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z))) <= sc.box_bound);
+            if (STAGED) {
+                float4* const mine = wave_rays_lds + (r * 64 + lane) * 3;
+                mine[0] = make_float4(o[r].x, o[r].y, o[r].z, grow[r]);
+                mine[1] = make_float4(d[r].x, d[r].y, d[r].z, 0.0f);
+                mine[2] = make_float4(box_ray[r].inv.x, box_ray[r].inv.y, box_ray[r].inv.z, 0.0f);
+            }
             d[r] = normalise(d[r]);   // for the bound of the wave: reflected directions drift off unit length
             wave_slots[r * 64 + lane] = slot[r];
         }
@@ -1168,21 +1197,19 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             for (uint32_t i = lane; i < q2_count; i += 64) {
                 const uint32_t e = q2[i];
                 const uint32_t s = wave_slots[e >> 24];
-                const V3 o{st.ox[s], st.oy[s], st.oz[s]};
-                const V3 dd{st.dx[s], st.dy[s], st.dz[s]};
+                const PairRay pr = pair_ray(e >> 24);
                 uint32_t k;
-                const float t = pretests_then_full(sc, load_tri_pair(sc, e & NODE_MASK), o, dd, n_full, k);
+                const float t = pretests_then_full(sc, load_tri_pair(sc, e & NODE_MASK), pr.o, pr.d, n_full, k);
                 if (t < FLT_MAX) atomicMin(&st.key[s], pack_hit(t, k));
             }
         } else if (PRIM == 1) {
             for (uint32_t i = lane; i < q2_count; i += 64) {
                 const uint32_t e = q2[i];
                 const uint32_t s = wave_slots[e >> 24];
-                const V3 o{st.ox[s], st.oy[s], st.oz[s]};
-                const V3 dd{st.dx[s], st.dy[s], st.dz[s]};
+                const PairRay pr = pair_ray(e >> 24);
                 const uint32_t k = h.k_of[e & NODE_MASK];
                 const float4* __restrict__ rec = sc.ell + static_cast<size_t>(k) * 6;
-                const float t = hit_ellipsoid(o, dd, rec[0], rec[1], rec[2], rec[3], rec[4], rec[5]);
+                const float t = hit_ellipsoid(pr.o, pr.d, rec[0], rec[1], rec[2], rec[3], rec[4], rec[5]);
                 n_full++;
                 if (t < FLT_MAX) atomicMin(&st.key_ell[s], pack_hit(t, k));
             }
@@ -1190,10 +1217,9 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             for (uint32_t i = lane; i < q2_count; i += 64) {
                 const uint32_t e = q2[i];
                 const uint32_t s = wave_slots[e >> 24];
-                const V3 o{st.ox[s], st.oy[s], st.oz[s]};
-                const V3 dd{st.dx[s], st.dy[s], st.dz[s]};
+                const PairRay pr = pair_ray(e >> 24);
                 const uint32_t k = h.k_of[e & NODE_MASK];
-                const float t = hit_sphere(o, dd, sc.sph[k]);
+                const float t = hit_sphere(pr.o, pr.d, sc.sph[k]);
                 n_full++;
                 if (t < FLT_MAX) atomicMin(&st.key_sph[s], pack_hit_signed(t, k));
             }
@@ -1210,11 +1236,10 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
         for (uint32_t i0 = 0; i0 < in_count; i0 += 64) {
             const bool active = i0 + lane < in_count;
             const uint32_t e = q_in[active ? i0 + lane : 0u];
-            const uint32_t s = wave_slots[e >> 24], first = (e & NODE_MASK) * CLUSTER;
-            const V3 o{st.ox[s], st.oy[s], st.oz[s]};
-            const V3 dd{st.dx[s], st.dy[s], st.dz[s]};
-            const BoxRay ray = make_box_ray(o, dd, FLT_MAX);
-            const float gr = GROWN ? sphere_growth(dd, sc.box_bound) : 0.0f;
+            const uint32_t first = (e & NODE_MASK) * CLUSTER;
+            const PairRay pr = pair_ray(e >> 24);
+            const BoxRay ray{pr.o, pr.inv, FLT_MAX};
+            const float gr = pr.grow;
             const uint32_t last = n_child - 1u;
             static_assert(CLUSTER % WALK_BATCH == 0 && WALK_BATCH % 4 == 0, "the walk takes WALK_BATCH children at a time, pushed four by four");
 #pragma nounroll
@@ -1544,6 +1569,9 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     constexpr uint32_t WAVE_LDS = N_QUEUES * QCAP + 64 * R;   // per wave: one queue per level ((ray, top node), (ray, cluster), (ray, leaf), with LEVELS = 4 also (ray, super node)), slot table
     __shared__ uint32_t lds_queue[WALK ? (BLOCK / 64) * WAVE_LDS : 1];
     __shared__ uint32_t lds_blocked[BLOCK];   // bit r: ray r of that thread is blocked (set by drains)
+    // the wave's shadow rays, staged once for the lanes that walk their pairs: (o, limit) (d, -) (1/d, limit of the box test) per ray
+    constexpr bool STAGED = WALK && RT_STAGE_RAYS(R, LEVELS);
+    __shared__ float4 lds_rays[STAGED ? (BLOCK / 64) * 64 * R * 3 : 1];
     const uint32_t n_rays = st.counts[bounce + 1];
     ScanSplit split;
     if (!WALK) {
@@ -1581,6 +1609,12 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             o[r] = s.o;
             d[r] = s.d;
             box_ray[r] = make_box_ray(s.o, s.d, LIMITED ? s.limit : FLT_MAX);
+            if (STAGED) {
+                float4* const mine = lds_rays + ((threadIdx.x >> 6) * (64 * R) + r * 64 + (threadIdx.x & 63u)) * 3;
+                mine[0] = make_float4(s.o.x, s.o.y, s.o.z, s.limit);
+                mine[1] = make_float4(s.d.x, s.d.y, s.d.z, 0.0f);
+                mine[2] = make_float4(box_ray[r].inv.x, box_ray[r].inv.y, box_ray[r].inv.z, box_ray[r].limit);
+            }
             unsafe |= !(fmaxf(fabsf(s.o.x), fmaxf(fabsf(s.o.y), fabsf(s.o.z))) <= sc.box_bound);
             if (!point) unsafe |= !(vdot(s.d, s.d) <= SPH_DIR_CHECK);   // a directional light's direction is the caller's: the pre-tests and the spheres' boxes need unit length
             blocked[r] = (st.blocked[slot[r]] & light_bit) != 0u;
@@ -1606,6 +1640,21 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     uint32_t* const wave_slots = q0 + N_QUEUES * QCAP;     // slot of ray r*64 + lane
     uint32_t q0_count = 0, q1_count = 0, q2_count = 0, qs_count = 0, n_full = 0, n_queued = 0;
     unsigned long long n_pairs = 0;
+    // shadow ray number `ray` of the wave (r*64 + lane of its owner) for the lane that handles one of its pairs
+    struct PairRay { ShadowRay s; BoxRay box; };
+    auto pair_ray = [&](uint32_t ray) __attribute__((always_inline)) {
+        PairRay p;
+        if (STAGED) {
+            const float4* __restrict__ rec = lds_rays + (wave * (64 * R) + ray) * 3;
+            const float4 a = rec[0], b = rec[1], c = rec[2];
+            p.s = ShadowRay{xyz(a), xyz(b), a.w};
+            p.box = BoxRay{xyz(a), xyz(c), c.w};
+        } else {
+            p.s = make_shadow_ray(st, wave_slots[ray], point, lv);
+            p.box = make_box_ray(p.s.o, p.s.d, LIMITED ? p.s.limit : FLT_MAX);
+        }
+        return p;
+    };
     // blocked bits of the wave's rays live in lds_blocked[thread that holds the ray], bit r; ray = r*64 + lane
     auto ray_blocked = [&](uint32_t ray) {
         return ((__hip_atomic_load(&lds_blocked[wave * 64u + (ray & 63u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> (ray >> 6)) & 1u) != 0u;
@@ -1617,7 +1666,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             for (uint32_t i = lane; i < q2_count; i += 64) {
                 const uint32_t e = q2[i];
                 const uint32_t ray = e >> 24;
-                const ShadowRay s = make_shadow_ray(st, wave_slots[ray], point, lv);
+                const ShadowRay s = pair_ray(ray).s;
                 uint32_t k;
                 if (pretests_then_full(sc, load_tri_pair(sc, e & NODE_MASK), s.o, s.d, n_full, k) < s.limit) atomicOr(&lds_blocked[wave * 64u + (ray & 63u)], 1u << (ray >> 6));
             }
@@ -1625,7 +1674,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             for (uint32_t i = lane; i < q2_count; i += 64) {
                 const uint32_t e = q2[i];
                 const uint32_t ray = e >> 24;
-                const ShadowRay s = make_shadow_ray(st, wave_slots[ray], point, lv);
+                const ShadowRay s = pair_ray(ray).s;
                 n_full++;
                 if (hit_sphere(s.o, s.d, sc.sph[h.k_of[e & NODE_MASK]]) < s.limit) atomicOr(&lds_blocked[wave * 64u + (ray & 63u)], 1u << (ray >> 6));
             }
@@ -1633,7 +1682,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             for (uint32_t i = lane; i < q2_count; i += 64) {
                 const uint32_t e = q2[i];
                 const uint32_t ray = e >> 24;
-                const ShadowRay s = make_shadow_ray(st, wave_slots[ray], point, lv);
+                const ShadowRay s = pair_ray(ray).s;
                 const uint32_t k = h.k_of[e & NODE_MASK];
                 const float4* __restrict__ rec = sc.ell + static_cast<size_t>(k) * 6;
                 const V3 l2 = point ? xyz(sc.ell_light[static_cast<size_t>(light - sc.has_directional) * sc.n_ell + k]) : V3{0.0f, 0.0f, 0.0f};
@@ -1658,8 +1707,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             const uint32_t e = q_in[active ? i0 + lane : 0u];
             const uint32_t first = (e & NODE_MASK) * CLUSTER;
             active = active && !ray_blocked(e >> 24);
-            const ShadowRay s = make_shadow_ray(st, wave_slots[e >> 24], point, lv);
-            const BoxRay ray = make_box_ray(s.o, s.d, LIMITED ? s.limit : FLT_MAX);
+            const BoxRay ray = pair_ray(e >> 24).box;
             const uint32_t last = n_child - 1u;
             static_assert(CLUSTER % WALK_BATCH == 0 && WALK_BATCH % 4 == 0, "the walk takes WALK_BATCH children at a time, pushed four by four");
 #pragma nounroll
