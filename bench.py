@@ -79,11 +79,19 @@ def main():
     import torch.distributed as dist
     from raytracer_amd import abi, api, distributed
 
+    # Rehearsal on a box with one GPU: RT_BENCH_REHEARSAL=1 puts every rank on device 0 and exchanges through gloo
+    # (RCCL refuses two ranks on one device); the numbers of such a run mean nothing, its frame check does.
+    rehearsal = os.environ.get("RT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     api.init(local_rank)
 
     fi, label, parse_s = load_workload(api, args.workload, args.width, args.height, args.maxdepth)
@@ -97,7 +105,11 @@ def main():
     stride = distributed.stride_tiles(prm, world)      # tiles per rank in the gathered buffer
     assert api.rank_tile_count(prm) == len(distributed.rank_tiles(prm, rank, world)) <= stride
 
-    tiles = torch.zeros(stride * TILE_BYTES, dtype=torch.uint8, device=device)
+    # Two tile buffers: while the ranks exchange the tiles of frame k (one RCCL all-gather over xGMI,
+    # asynchronous on torch's stream), frame k+1 is already being traced into the other buffer.
+    tiles = [torch.zeros(stride * TILE_BYTES, dtype=torch.uint8, device=device) for _ in range(2)]
+    gathered = [torch.zeros(world * stride * TILE_BYTES, dtype=torch.uint8, device=device) if world > 1 else tiles[i] for i in range(2)]
+    exchanged = [None, None]
     frame = torch.zeros(fi.height * fi.width * 3, dtype=torch.uint8, device=device) if rank == 0 else None
 
     def barrier():
@@ -105,22 +117,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        st = scene.render_tiles_device(cam, prm, tiles.data_ptr(), want_stats=True)   # returns with its stream idle
-        gathered = distributed.all_gather_tiles(tiles, world)   # RCCL over xGMI: the framebuffer exchange
-        if world > 1:
-            torch.cuda.synchronize()
+    def finish(k):
+        """Frame k: wait for its exchange, then rank 0 scatters the gathered tiles into the image."""
+        if exchanged[k % 2] is not None:
+            exchanged[k % 2].synchronize()
         if rank == 0:
-            api.assemble_tiles_device(gathered.data_ptr(), stride, prm, frame.data_ptr())
-        return st
+            api.assemble_tiles_device(gathered[k % 2].data_ptr(), stride, prm, frame.data_ptr())
 
-    for _ in range(args.warmup):
-        step()
+    def run(n):
+        stats = []
+        for k in range(n):
+            stats.append(scene.render_tiles_device(cam, prm, tiles[k % 2].data_ptr(), want_stats=True))   # returns with its streams idle
+            if k:
+                finish(k - 1)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered[k % 2], tiles[k % 2])
+                exchanged[k % 2] = torch.cuda.Event()
+                exchanged[k % 2].record()
+        if n:
+            finish(n - 1)
+        return stats
+
+    run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    stats = []
-    for _ in range(args.steps):
-        stats.append(step())
+    stats = run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -204,6 +225,10 @@ def main():
             "per_rank_max_ms": {k: v / args.steps for k, v in rank_max.items()},
             "setup_ms": {"parse_scene_file": parse_s * 1e3, "scene_create": scene_create_s * 1e3},   # rank 0, outside the timed steps
         }
+        if not args.brute_force:
+            # the frame the ranks assembled in the last step against one rendered by this rank alone (outside the timed steps)
+            alone = scene.render(cam, fi.params(max_bounce_count=depth, flags=flags))
+            out["frame_identical_to_single_rank_render"] = bool((alone["rgb"].reshape(-1) == frame.cpu().numpy()).all())
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(api, abi, fi, cam, scene, depth, args.cpu_crop)
         print(json.dumps(out), flush=True)
