@@ -12,6 +12,6 @@ db = sqlite3.connect(glob.glob(sys.argv[1] + "/*.db")[0])
 tot = 0
 for name, calls, total, avg, pct in db.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()[:12]:
     tot += total
-    print("%6d calls %10.3f ms total %9.4f ms avg %6.2f%%  %s" % (calls, total / 1e6, avg / 1e6, pct, name.replace("(anonymous namespace)::", "").split("(")[0]))
-print("sum of kernel time over 3 renders: %.3f ms" % (tot / 1e6))
+    print("%6d calls %10.3f ms total %9.4f ms avg %6.2f%%  %s" % (calls, total / 1e3, avg / 1e3, pct, name.replace("(anonymous namespace)::", "").split("(")[0]))
+print("sum of kernel time over 3 renders: %.3f ms" % (tot / 1e3))
 PY
