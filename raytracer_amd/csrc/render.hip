@@ -1315,6 +1315,111 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     }
 }
 
+// Closest hit for rays that leave the eye (bounce 0).  The 64 rays of a wave are the 16 samples
+// of four neighbouring pixels and share their origin, so the bound of the wave (make_packet) is
+// almost as narrow as a single ray: the whole hierarchy is walked ONCE PER WAVE against that bound
+// - top nodes one per lane, then the 16 clusters of a kept top node and the 16 leaves of a kept
+// cluster on 16 lanes each - and only the leaves the wave can reach are tested per ray (box test,
+// then the full test of the kind; for triangles through the two-stage pre-test).  No queues: the
+// closest hit is a per-lane running minimum, ties going to the smaller scan index as in the
+// brute-force scan; it is merged into st.key* by atomicMin because a small launch is split over
+// segments of the top level (scan_split).  A node the wave's bound cannot reach holds no hit for
+// any of its rays, so the result is that of the per-ray walk.
+template <int PRIM>
+__global__ void __launch_bounds__(BLOCK) k_closest_packet(DevScene sc, State st, uint32_t bounce) {
+    const Hierarchy& h = PRIM == 0 ? sc.th : (PRIM == 1 ? sc.eh : sc.sh);
+    const uint32_t n_rays = st.counts[bounce];
+    const uint32_t* __restrict__ list_in = st.list[bounce & 1u];
+    const ScanSplit split = scan_split(n_rays, BLOCK, h.n_tops, 16u);
+    if (!split.active) return;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t i = split.ray_base + wave * 64 + lane;
+    const bool valid = i < n_rays;
+    const uint32_t slot = list_in[valid ? i : split.ray_base];
+    const V3 o{st.ox[slot], st.oy[slot], st.oz[slot]};
+    const V3 d{st.dx[slot], st.dy[slot], st.dz[slot]};
+    const BoxRay ray = make_box_ray(o, d, FLT_MAX);
+    const float grow = PRIM == 2 ? sphere_growth(d, sc.box_bound) : 0.0f;
+    const bool unsafe = !(fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))) <= sc.box_bound);
+    Packet packet;
+    {
+        const V3 dn[1] = {normalise(d)};
+        const V3 on[1] = {o};
+        const bool vn[1] = {valid};
+        packet = make_packet<1>(dn, on, vn);
+        if (PRIM == 2) packet.rho += wave_max(valid ? grow : 0.0f);
+        packet = uniform_packet(packet);
+    }
+    const bool keep_all = __any(unsafe);
+    const uint32_t wave_rays = __popcll(__ballot(valid));
+    float best_t = FLT_MAX;
+    uint32_t best_k = 0xFFFFFFFFu, n_full = 0;
+    unsigned long long n_pairs = 0, n_queued = 0;
+    const uint32_t sub = lane & 15u;   // the child a lane looks at, one level down
+
+    for (uint32_t c0 = split.first_prim; c0 < split.end_prim; c0 += 64) {
+        const size_t mine_at = min(c0 + lane, split.end_prim - 1u);
+        const bool reach = packet_sphere_keeps(packet, box_sphere(h.top_box[mine_at * 2], h.top_box[mine_at * 2 + 1]));
+        unsigned long long top_mask = __ballot((reach || keep_all) && c0 + lane < split.end_prim);
+        while (top_mask) {
+            const uint32_t top = c0 + static_cast<uint32_t>(__builtin_ctzll(top_mask));
+            top_mask &= top_mask - 1ull;
+            const uint32_t cluster_at = top * CLUSTER + sub;
+            const size_t cl = min(cluster_at, h.n_clusters - 1u);
+            const bool cl_reach = packet_sphere_keeps(packet, box_sphere(h.cl_box[cl * 2], h.cl_box[cl * 2 + 1]));
+            unsigned long long cl_mask = __ballot((cl_reach || keep_all) && lane < CLUSTER && cluster_at < h.n_clusters);
+            while (cl_mask) {
+                const uint32_t cluster = top * CLUSTER + static_cast<uint32_t>(__builtin_ctzll(cl_mask));
+                cl_mask &= cl_mask - 1ull;
+                const uint32_t leaf_at = cluster * CLUSTER + sub;
+                const size_t lf = min(leaf_at, h.n - 1u);
+                const float4 leaf_lo = h.leaf_box[lf * 2], leaf_hi = h.leaf_box[lf * 2 + 1];
+                const bool leaf_reach = packet_sphere_keeps(packet, box_sphere(leaf_lo, leaf_hi));
+                unsigned long long leaf_mask = __ballot((leaf_reach || keep_all) && lane < CLUSTER && leaf_at < h.n);
+                while (leaf_mask) {
+                    const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(leaf_mask));
+                    leaf_mask &= leaf_mask - 1ull;
+                    const uint32_t pos = cluster * CLUSTER + bit;
+                    // every lane: its own ray against the leaf at position pos
+                    const float4 lo = readlane4(leaf_lo, bit), hi = readlane4(leaf_hi, bit);
+                    n_pairs += wave_rays;
+                    const bool in_box = valid && ((PRIM == 2 ? box_keeps_grown(ray, lo, hi, grow) : box_keeps(ray, lo, hi)) || keep_all);
+                    n_queued += __popcll(__ballot(in_box));
+                    if (in_box) {
+                        float t;
+                        uint32_t k;
+                        if (PRIM == 0) {
+                            t = pretests_then_full(sc, load_tri_pair(sc, pos), o, d, n_full, k);
+                        } else if (PRIM == 1) {
+                            k = h.k_of[pos];
+                            const float4* __restrict__ rec = sc.ell + static_cast<size_t>(k) * 6;
+                            t = hit_ellipsoid(o, d, rec[0], rec[1], rec[2], rec[3], rec[4], rec[5]);
+                            n_full++;
+                        } else {
+                            k = h.k_of[pos];
+                            t = hit_sphere(o, d, sc.sph[k]);
+                            n_full++;
+                        }
+                        if (t < FLT_MAX && (t < best_t || (t == best_t && k < best_k))) { best_t = t; best_k = k; }
+                    }
+                }
+            }
+        }
+    }
+    if (valid && best_k != 0xFFFFFFFFu) {
+        if (PRIM == 0) atomicMin(&st.key[slot], pack_hit(best_t, best_k));
+        else if (PRIM == 1) atomicMin(&st.key_ell[slot], pack_hit(best_t, best_k));
+        else atomicMin(&st.key_sph[slot], pack_hit_signed(best_t, best_k));
+    }
+    if (PRIM == 0) block_add_stat(stat_slot(st, ST_FULL_TESTS), n_full);
+    if (lane == 0 && n_pairs) atomicAdd(stat_slot(st, ST_PAIR_PRETESTS), n_pairs);
+    if (lane == 0 && n_queued) atomicAdd(stat_slot(st, ST_QUEUED), n_queued);
+    {   // FLOP executed in per-ray tests (n_full is per lane; the others are wave totals)
+        constexpr unsigned long long CHILD = 24, LEAF = PRIM == 0 ? 40 : (PRIM == 1 ? 95 : 19), FULL = PRIM == 0 ? 54 : 0;
+        block_add_stat(stat_slot(st, ST_FLOP), FULL * n_full + (lane == 0 ? CHILD * n_pairs + LEAF * n_queued : 0ull));
+    }
+}
+
 template <int R>
 __global__ void __launch_bounds__(BLOCK) k_closest_sph(DevScene sc, State st, uint32_t bounce) {
     __shared__ float4 lds[TILE_PRIMS];
@@ -2034,6 +2139,15 @@ constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;   // brute-force scans
 // wave costs more than that, so big scenes (the synthetic one: 3907 top nodes) take two, and start
 // the walk one level higher, at the super nodes (synthetic scene: 593 -> 561 ms; scene7 would lose: 25 -> 30 ms).
 constexpr uint32_t TOPS_FOR_DEEP_WALK = 1024;
+// Kinds whose eye rays are walked once per wave (k_closest_packet): bit 0 triangles, 1 ellipsoids, 2 spheres.
+// It pays where the leaf test needs little data (scene5, 1000 spheres, at 3840x2160: 26.4 -> 23.4 ms); for
+// triangles the chain of dependent loads down to the 64-byte records of every leaf the wave can reach makes
+// it lose (scene7: 24.8 -> 34.5 ms).  RT_AMD_EYE_PACKETS in the environment overrides it (tuning).
+constexpr uint32_t EYE_PACKET_KINDS = 6;
+bool packet_walk_for_eye_rays(int prim) {
+    static const uint32_t kinds = [] { const char* e = std::getenv("RT_AMD_EYE_PACKETS"); return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : EYE_PACKET_KINDS; }();
+    return (kinds >> prim) & 1u;
+}
 // A kind with at most this many slots is scanned by brute force even in the default mode: the walk of
 // a hierarchy costs more than it saves there (measured crossover: 32 to 64 slots for every kind;
 // scene6, 40 + 8 + 8 slots and 1.15 G rays at 3840x2160: 208 ms walking, 141 ms brute force).
@@ -2277,6 +2391,13 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         auto closest_scans = [&](uint32_t b, hipStream_t on) {
             const State sb = state_of(b);
             auto hierarchy_scan = [&](int prim) {   // one or two rays per lane, three or four levels (TOPS_FOR_DEEP_WALK)
+                if (b == 0 && packet_walk_for_eye_rays(prim)) {   // rays from the eye: one walk per wave
+                    const dim3 grid(blocks_for(1));
+                    if (prim == 0) hipLaunchKernelGGL(k_closest_packet<0>, grid, dim3(BLOCK), 0, on, sc, sb, b);
+                    else if (prim == 1) hipLaunchKernelGGL(k_closest_packet<1>, grid, dim3(BLOCK), 0, on, sc, sb, b);
+                    else hipLaunchKernelGGL(k_closest_packet<2>, grid, dim3(BLOCK), 0, on, sc, sb, b);
+                    return;
+                }
                 const bool deep = force_deep || hierarchy_of(sc, prim).n_tops > TOPS_FOR_DEEP_WALK;
                 const dim3 grid(blocks_for(deep ? 2 : 1));
                 if (prim == 0) launch_closest_scan<0>(deep, grid, on, sc, sb, b);
