@@ -92,6 +92,7 @@ constexpr uint32_t SAMPLES_PER_TILE = RT_TILE * RT_TILE * RT_SAMPLES_PER_PIXEL; 
 struct Hierarchy {
     const uint32_t* k_of;
     const float4 *leaf_box, *cl_box, *top_box, *super_box;
+    const uint4 *cl_nodes, *top_nodes, *super_nodes;   // the children of every cluster / top node / super node, packed (PackedChildren)
     uint32_t n, n_clusters, n_tops, n_supers;
 };
 
@@ -348,6 +349,24 @@ DEV bool box_keeps_grown(const BoxRay& r, float4 lo, float4 hi, float grow) {
     hi.x += grow; hi.y += grow; hi.z += grow;
     return box_keeps(r, lo, hi);
 }
+// The CLUSTER = 16 children of a node in one 128-byte record (8 x uint4), which is what a lane that
+// walks the node fetches: w[0] = (base.xyz, scale.x), w[1] = (scale.y, scale.z, -, -) as float bits,
+// w[2..7] = byte u of each: lo.x, hi.x, lo.y, hi.y, lo.z, hi.z of child u in units of `scale` above
+// `base`.  A child's box as decoded here, fma(q, scale, base), contains its box record: the builder
+// (k_prep_packed_children) evaluates this very expression and moves q until it does.  A node with a
+// child that is not a finite box has base = NaN: every child decodes to NaN and keeps every ray.
+// Against 16 separate 32-byte records this is a quarter of the bytes and 8 loads instead of 32.
+DEV uint32_t dword_of(uint4 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+DEV float packed_coord(uint4 bytes, int child, float scale, float base) {
+    return fma_(static_cast<float>((dword_of(bytes, child >> 2) >> (8 * (child & 3))) & 255u), scale, base);
+}
+DEV void decode_child(const uint4 (&w)[8], int child, float4& lo, float4& hi) {
+    const float bx = __uint_as_float(w[0].x), by = __uint_as_float(w[0].y), bz = __uint_as_float(w[0].z);
+    const float sx = __uint_as_float(w[0].w), sy = __uint_as_float(w[1].x), sz = __uint_as_float(w[1].y);
+    lo = make_float4(packed_coord(w[2], child, sx, bx), packed_coord(w[4], child, sy, by), packed_coord(w[6], child, sz, bz), 0.0f);
+    hi = make_float4(packed_coord(w[3], child, sx, bx), packed_coord(w[5], child, sy, by), packed_coord(w[7], child, sz, bz), 0.0f);
+}
+
 // Sphere (centre, radius^2) around a box record, for the per-wave test (packet_sphere_keeps)
 DEV float4 box_sphere(float4 lo, float4 hi) {
     const V3 c{0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
@@ -661,6 +680,63 @@ __global__ void __launch_bounds__(BLOCK) k_prep_cluster_box(const float4* __rest
     if (all) { lo = make_float4(-inf, -inf, -inf, 0.0f); hi = make_float4(inf, inf, inf, 0.0f); }
     out[static_cast<size_t>(c) * 2] = lo;
     out[static_cast<size_t>(c) * 2 + 1] = hi;
+}
+
+// PackedChildren of every node of one level from the box records of the level below
+__global__ void __launch_bounds__(BLOCK) k_prep_packed_children(const float4* __restrict__ member, uint32_t n_member, uint32_t n_nodes, uint4* __restrict__ out) {
+    static_assert(CLUSTER == 16, "a packed record holds 16 children");
+    const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= n_nodes) return;
+    const uint32_t first = c * CLUSTER, count = min(CLUSTER, n_member - first);
+    const float inf = __builtin_inff();
+    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+    bool bad = false;
+    for (uint32_t t = 0; t < count; ++t) {
+        const float4 l = member[static_cast<size_t>(first + t) * 2], h = member[static_cast<size_t>(first + t) * 2 + 1];
+        const float cl[3] = {l.x, l.y, l.z}, ch[3] = {h.x, h.y, h.z};
+        for (int a = 0; a < 3; ++a) {
+            if (!(fabsf(cl[a]) < inf) || !(fabsf(ch[a]) < inf) || !(cl[a] <= ch[a])) bad = true;
+            lo[a] = fminf(lo[a], cl[a]); hi[a] = fmaxf(hi[a], ch[a]);
+        }
+    }
+    float scale[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t bytes[6][4] = {};
+    if (!bad) {
+        for (int a = 0; a < 3; ++a) {
+            const float ext = hi[a] - lo[a];
+            scale[a] = ext > 0.0f ? nextafterf(ext / 255.0f, inf) * 1.000001f : 0.0f;
+            if (!(scale[a] < inf) || fma_(255.0f, scale[a], lo[a]) < hi[a]) bad = true;
+        }
+    }
+    if (!bad) {
+        for (uint32_t t = 0; t < count; ++t) {
+            const float4 l = member[static_cast<size_t>(first + t) * 2], h = member[static_cast<size_t>(first + t) * 2 + 1];
+            const float cl[3] = {l.x, l.y, l.z}, ch[3] = {h.x, h.y, h.z};
+            for (int a = 0; a < 3; ++a) {
+                float ql = 0.0f, qh = 0.0f;
+                if (scale[a] > 0.0f) {
+                    ql = fminf(fmaxf(floorf((cl[a] - lo[a]) / scale[a]), 0.0f), 255.0f);
+                    qh = fminf(fmaxf(ceilf((ch[a] - lo[a]) / scale[a]), 0.0f), 255.0f);
+                    while (ql > 0.0f && fma_(ql, scale[a], lo[a]) > cl[a]) ql -= 1.0f;    // the decoded box must contain the record
+                    while (qh < 255.0f && fma_(qh, scale[a], lo[a]) < ch[a]) qh += 1.0f;
+                }
+                if (fma_(ql, scale[a], lo[a]) > cl[a] || fma_(qh, scale[a], lo[a]) < ch[a]) bad = true;
+                bytes[2 * a][t >> 2] |= static_cast<uint32_t>(ql) << (8 * (t & 3));
+                bytes[2 * a + 1][t >> 2] |= static_cast<uint32_t>(qh) << (8 * (t & 3));
+            }
+        }
+    }
+    uint4* o = out + static_cast<size_t>(c) * 8;
+    if (bad) {
+        const uint32_t nan = 0x7FC00000u;
+        o[0] = make_uint4(nan, nan, nan, 0u);
+        o[1] = make_uint4(0u, 0u, 0u, 0u);
+        for (int w = 2; w < 8; ++w) o[w] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    o[0] = make_uint4(__float_as_uint(lo[0]), __float_as_uint(lo[1]), __float_as_uint(lo[2]), __float_as_uint(scale[0]));
+    o[1] = make_uint4(__float_as_uint(scale[1]), __float_as_uint(scale[2]), 0u, 0u);
+    for (int w = 0; w < 6; ++w) o[2 + w] = make_uint4(bytes[w][0], bytes[w][1], bytes[w][2], bytes[w][3]);
 }
 
 // ---- bounding records of the ellipsoids (all in double) ----
@@ -1016,13 +1092,9 @@ constexpr uint32_t QCAP = RT_QCAP, PUSH_MAX = 256;
 #ifndef RT_STAGE_RAYS
 #define RT_STAGE_RAYS(R, LEVELS) ((LEVELS) == 3)
 #endif
-#ifndef RT_WALK_BATCH
-#define RT_WALK_BATCH 4
-#endif
 #ifndef RT_SCAN_ATTR
 #define RT_SCAN_ATTR
 #endif
-constexpr int WALK_BATCH = RT_WALK_BATCH;   // child records a lane has in flight while it walks a node
 constexpr uint32_t NODE_MASK = 0xFFFFFFu;
 // For every set bit b < n_bits of a lane's `bits`, append base + b*step.  Entries of one bit are contiguous, in lane order.
 DEV void push_bits(uint32_t* q, uint32_t& count, uint32_t bits, uint32_t n_bits, uint32_t base, uint32_t step) {
@@ -1230,7 +1302,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     };
     // (ray, node) pairs: one pair per lane, the lane walks the CLUSTER children of its node and queues
     // the ones its ray may reach one level down
-    auto walk = [&](uint32_t* q_in, uint32_t& in_count, const float4* __restrict__ child, uint32_t n_child,
+    auto walk = [&](uint32_t* q_in, uint32_t& in_count, const uint4* __restrict__ nodes, uint32_t n_child,
                     uint32_t* q_out, uint32_t& out_count, auto&& drain_out) __attribute__((always_inline)) {
         wave_sync();
         for (uint32_t i0 = 0; i0 < in_count; i0 += 64) {
@@ -1241,30 +1313,26 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             const BoxRay ray{pr.o, pr.inv, FLT_MAX};
             const float gr = pr.grow;
             const uint32_t last = n_child - 1u;
-            static_assert(CLUSTER % WALK_BATCH == 0 && WALK_BATCH % 4 == 0, "the walk takes WALK_BATCH children at a time, pushed four by four");
-#pragma nounroll
-            for (uint32_t t0 = 0; t0 < CLUSTER; t0 += WALK_BATCH) {     // WALK_BATCH records in flight per lane
-                float4 lo[WALK_BATCH], hi[WALK_BATCH];
+            uint4 w[8];
+            const uint4* __restrict__ src = nodes + static_cast<size_t>(e & NODE_MASK) * 8;
 #pragma unroll
-                for (int u = 0; u < WALK_BATCH; ++u) {
-                    const size_t c = min(first + t0 + u, last);
-                    lo[u] = child[c * 2]; hi[u] = child[c * 2 + 1];
-                }
-                uint32_t keep_bits = 0;
+            for (int v = 0; v < 8; ++v) w[v] = src[v];
+            uint32_t keep_bits = 0;
 #pragma unroll
-                for (int u = 0; u < WALK_BATCH; ++u) {
-                    // no short circuit: the test is cheaper than a branch around it
-                    const bool hit = GROWN ? box_keeps_grown(ray, lo[u], hi[u], gr) : box_keeps(ray, lo[u], hi[u]);
-                    const bool keep = (active & (first + t0 + u <= last)) & (hit | keep_all);
-                    keep_bits |= keep ? 1u << u : 0u;
-                }
+            for (int u = 0; u < static_cast<int>(CLUSTER); ++u) {
+                float4 lo, hi;
+                decode_child(w, u, lo, hi);
+                // no short circuit: the test is cheaper than a branch around it
+                const bool hit = GROWN ? box_keeps_grown(ray, lo, hi, gr) : box_keeps(ray, lo, hi);
+                const bool keep = (active & (first + u <= last)) & (hit | keep_all);
+                keep_bits |= keep ? 1u << u : 0u;
+            }
 #pragma nounroll
-                for (uint32_t half = 0; half < WALK_BATCH / 4; ++half) {     // not unrolled: one copy of the code behind drain_out
-                    const uint32_t bits = (keep_bits >> (4u * half)) & 15u;
-                    if (__any(bits != 0u)) {
-                        if (out_count + PUSH_MAX > QCAP) drain_out();
-                        push_bits(q_out, out_count, bits, 4u, (e & ~NODE_MASK) | (first + t0 + 4u * half), 1u);
-                    }
+            for (uint32_t quarter = 0; quarter < CLUSTER / 4; ++quarter) {     // not unrolled: one copy of the code behind drain_out
+                const uint32_t bits = (keep_bits >> (4u * quarter)) & 15u;
+                if (__any(bits != 0u)) {
+                    if (out_count + PUSH_MAX > QCAP) drain_out();
+                    push_bits(q_out, out_count, bits, 4u, (e & ~NODE_MASK) | (first + 4u * quarter), 1u);
                 }
             }
         }
@@ -1272,9 +1340,9 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
         wave_sync();
         in_count = 0;
     };
-    auto drain1 = [&]() __attribute__((always_inline)) { walk(q1, q1_count, h.leaf_box, h.n, q2, q2_count, drain2); };
-    auto drain0 = [&]() __attribute__((always_inline)) { walk(q0, q0_count, h.cl_box, h.n_clusters, q1, q1_count, drain1); };
-    auto drain_supers = [&]() __attribute__((always_inline)) { walk(qs, qs_count, h.top_box, h.n_tops, q0, q0_count, drain0); };
+    auto drain1 = [&]() __attribute__((always_inline)) { walk(q1, q1_count, h.cl_nodes, h.n, q2, q2_count, drain2); };
+    auto drain0 = [&]() __attribute__((always_inline)) { walk(q0, q0_count, h.top_nodes, h.n_clusters, q1, q1_count, drain1); };
+    auto drain_supers = [&]() __attribute__((always_inline)) { walk(qs, qs_count, h.super_nodes, h.n_tops, q0, q0_count, drain0); };
     // the level the scan starts at: its boxes are tested one per lane against the wave's bound, then per ray
     const float4* __restrict__ first_box = LEVELS == 4 ? h.super_box : h.top_box;
     uint32_t* const q_first = LEVELS == 4 ? qs : q0;
@@ -1804,7 +1872,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     };
     // (ray, node) pairs: one pair per lane, the lane walks the CLUSTER children of its node and queues
     // the ones its ray may reach one level down; pairs of rays that are blocked by now are dropped
-    auto walk = [&](uint32_t* q_in, uint32_t& in_count, const float4* __restrict__ child, uint32_t n_child,
+    auto walk = [&](uint32_t* q_in, uint32_t& in_count, const uint4* __restrict__ nodes, uint32_t n_child,
                     uint32_t* q_out, uint32_t& out_count, auto&& drain_out) __attribute__((always_inline)) {
         wave_sync();
         for (uint32_t i0 = 0; i0 < in_count; i0 += 64) {
@@ -1814,30 +1882,26 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             active = active && !ray_blocked(e >> 24);
             const BoxRay ray = pair_ray(e >> 24).box;
             const uint32_t last = n_child - 1u;
-            static_assert(CLUSTER % WALK_BATCH == 0 && WALK_BATCH % 4 == 0, "the walk takes WALK_BATCH children at a time, pushed four by four");
-#pragma nounroll
-            for (uint32_t t0 = 0; t0 < CLUSTER; t0 += WALK_BATCH) {     // WALK_BATCH records in flight per lane
-                float4 lo[WALK_BATCH], hi[WALK_BATCH];
+            uint4 w[8];
+            const uint4* __restrict__ src = nodes + static_cast<size_t>(e & NODE_MASK) * 8;
 #pragma unroll
-                for (int u = 0; u < WALK_BATCH; ++u) {
-                    const size_t c = min(first + t0 + u, last);
-                    lo[u] = child[c * 2]; hi[u] = child[c * 2 + 1];
-                }
-                uint32_t keep_bits = 0;
+            for (int v = 0; v < 8; ++v) w[v] = src[v];
+            uint32_t keep_bits = 0;
 #pragma unroll
-                for (int u = 0; u < WALK_BATCH; ++u) {
-                    // no short circuit: the test is cheaper than a branch around it
-                    const bool hit = box_keeps(ray, lo[u], hi[u]);
-                    const bool keep = (active & (first + t0 + u <= last)) & (hit | keep_all);
-                    keep_bits |= keep ? 1u << u : 0u;
-                }
+            for (int u = 0; u < static_cast<int>(CLUSTER); ++u) {
+                float4 lo, hi;
+                decode_child(w, u, lo, hi);
+                // no short circuit: the test is cheaper than a branch around it
+                const bool hit = box_keeps(ray, lo, hi);
+                const bool keep = (active & (first + u <= last)) & (hit | keep_all);
+                keep_bits |= keep ? 1u << u : 0u;
+            }
 #pragma nounroll
-                for (uint32_t half = 0; half < WALK_BATCH / 4; ++half) {     // not unrolled: one copy of the code behind drain_out
-                    const uint32_t bits = (keep_bits >> (4u * half)) & 15u;
-                    if (__any(bits != 0u)) {
-                        if (out_count + PUSH_MAX > QCAP) drain_out();
-                        push_bits(q_out, out_count, bits, 4u, (e & ~NODE_MASK) | (first + t0 + 4u * half), 1u);
-                    }
+            for (uint32_t quarter = 0; quarter < CLUSTER / 4; ++quarter) {     // not unrolled: one copy of the code behind drain_out
+                const uint32_t bits = (keep_bits >> (4u * quarter)) & 15u;
+                if (__any(bits != 0u)) {
+                    if (out_count + PUSH_MAX > QCAP) drain_out();
+                    push_bits(q_out, out_count, bits, 4u, (e & ~NODE_MASK) | (first + 4u * quarter), 1u);
                 }
             }
         }
@@ -1845,9 +1909,9 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
         wave_sync();
         in_count = 0;
     };
-    auto drain1 = [&]() __attribute__((always_inline)) { walk(q1, q1_count, h.leaf_box, h.n, q2, q2_count, drain2); };
-    auto drain0 = [&]() __attribute__((always_inline)) { walk(q0, q0_count, h.cl_box, h.n_clusters, q1, q1_count, drain1); };
-    auto drain_supers = [&]() __attribute__((always_inline)) { walk(qs, qs_count, h.top_box, h.n_tops, q0, q0_count, drain0); };
+    auto drain1 = [&]() __attribute__((always_inline)) { walk(q1, q1_count, h.cl_nodes, h.n, q2, q2_count, drain2); };
+    auto drain0 = [&]() __attribute__((always_inline)) { walk(q0, q0_count, h.top_nodes, h.n_clusters, q1, q1_count, drain1); };
+    auto drain_supers = [&]() __attribute__((always_inline)) { walk(qs, qs_count, h.super_nodes, h.n_tops, q0, q0_count, drain0); };
     // the level the scan starts at: its boxes are tested one per lane against the wave's bound, then per ray
     const float4* __restrict__ first_box = LEVELS == 4 ? h.super_box : h.top_box;
     uint32_t* const q_first = LEVELS == 4 ? qs : q0;
@@ -2278,6 +2342,9 @@ void build_boxes(const rt_scene* scene, float bound, hipStream_t stream) {
         hipLaunchKernelGGL(k_prep_cluster_box, cl_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(leaf), h.n, h.n_clusters, cl);
         hipLaunchKernelGGL(k_prep_cluster_box, top_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(cl), h.n_clusters, h.n_tops, top);
         hipLaunchKernelGGL(k_prep_cluster_box, super_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(top), h.n_tops, h.n_supers, super);
+        hipLaunchKernelGGL(k_prep_packed_children, cl_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(leaf), h.n, h.n_clusters, const_cast<uint4*>(h.cl_nodes));
+        hipLaunchKernelGGL(k_prep_packed_children, top_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(cl), h.n_clusters, h.n_tops, const_cast<uint4*>(h.top_nodes));
+        hipLaunchKernelGGL(k_prep_packed_children, super_grid, dim3(BLOCK), 0, stream, static_cast<const float4*>(top), h.n_tops, h.n_supers, const_cast<uint4*>(h.super_nodes));
     }
     scene->box_bound = bound;
 }
@@ -2747,13 +2814,18 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
         orders[prim] = cluster_order(centroid, good);
         uint32_t* k_of;
         float4 *leaf_box, *cl_box, *top_box, *super_box;
+        uint4 *cl_nodes, *top_nodes, *super_nodes;
         if ((rc = upload(s, orders[prim].data(), orders[prim].size(), &k_of))) return fail(rc);
         if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n) * 2, &leaf_box))) return fail(rc);
         if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n_clusters) * 2, &cl_box))) return fail(rc);
         if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n_tops) * 2, &top_box))) return fail(rc);
         if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n_supers) * 2, &super_box))) return fail(rc);
         h.k_of = k_of;
+        if ((rc = upload<uint4>(s, nullptr, static_cast<size_t>(h.n_clusters) * 8, &cl_nodes))) return fail(rc);
+        if ((rc = upload<uint4>(s, nullptr, static_cast<size_t>(h.n_tops) * 8, &top_nodes))) return fail(rc);
+        if ((rc = upload<uint4>(s, nullptr, static_cast<size_t>(h.n_supers) * 8, &super_nodes))) return fail(rc);
         h.leaf_box = leaf_box; h.cl_box = cl_box; h.top_box = top_box; h.super_box = super_box;
+        h.cl_nodes = cl_nodes; h.top_nodes = top_nodes; h.super_nodes = super_nodes;
         if (prim == 0) {
             float4* trif_pos;
             if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n) * 4, &trif_pos))) return fail(rc);
