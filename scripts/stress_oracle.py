@@ -17,9 +17,8 @@ import checkers
 from raytracer_amd import api, synth
 
 
-def main():
-    first, count = int(sys.argv[1]), int(sys.argv[2])
-    against_ref = len(sys.argv) > 3 and sys.argv[3] == "ref"
+def run(first, count, against_ref=False):
+    """Returns the number of scenes that differ."""
     api.init(0)
     oracle = checkers.load_ref() if against_ref else checkers.load_oracle()
     d = tempfile.mkdtemp()
@@ -63,7 +62,11 @@ def main():
         if (seed - first) % 10 == 9:
             print("seed %d done, %d mismatches so far" % (seed, bad), flush=True)
     print("stress: %d scenes, %d mismatches" % (count, bad))
-    sys.exit(1 if bad else 0)
+    return bad
+
+
+def main():
+    sys.exit(1 if run(int(sys.argv[1]), int(sys.argv[2]), len(sys.argv) > 3 and sys.argv[3] == "ref") else 0)
 
 
 if __name__ == "__main__":

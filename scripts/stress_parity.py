@@ -11,8 +11,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from raytracer_amd import abi, api, synth
 
 
-def main():
-    first, count = int(sys.argv[1]), int(sys.argv[2])
+def run(first, count):
+    """Returns the number of (scene, mode) pairs that differ."""
     api.init(0)
     d = tempfile.mkdtemp()
     bad = 0
@@ -39,11 +39,14 @@ def main():
                     seed, name, kw, int((g["ids"] != ref["ids"]).sum()), int((g["rgb"] != ref["rgb"]).any(axis=2).sum()),
                     g["stats"].shadow_blocked, ref["stats"].shadow_blocked), flush=True)
         scene.close()
-        os.remove(fi.filename) if hasattr(fi, "filename") else None
         if (seed - first) % 10 == 9:
             print("seed %d done, %d mismatches so far" % (seed, bad), flush=True)
     print("stress: %d scenes, %d mismatches" % (count, bad))
-    sys.exit(1 if bad else 0)
+    return bad
+
+
+def main():
+    sys.exit(1 if run(int(sys.argv[1]), int(sys.argv[2])) else 0)
 
 
 if __name__ == "__main__":
