@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_internal.h"
@@ -2597,51 +2598,85 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
 }
 
 // Cluster order of the primitives of one kind: the scan indices in the leaf order of a kd tree over
-// their centroids, degenerate and non-finite primitives last.  A range of more than CLUSTER*CLUSTER
-// triangles is split at a multiple of CLUSTER*CLUSTER near its middle along its longest axis,
-// a smaller one at a multiple of CLUSTER, so that every aligned group of CLUSTER positions is one
-// leaf (a compact patch) and every aligned group of CLUSTER clusters one subtree.
-// Only the box records and the triangles' pre-test records are stored in this order; it decides
-// which primitives share a box and nothing else, so any permutation gives the same image.
-std::vector<uint32_t> cluster_order(const std::vector<float>& centroid, const std::vector<uint8_t>& good) {
-    const uint32_t n = static_cast<uint32_t>(good.size());
-    std::vector<uint32_t> order, rejects;
-    order.reserve(n);
-    for (uint32_t k = 0; k < n; ++k) (good[k] ? order : rejects).push_back(k);
-    std::vector<std::pair<uint32_t, uint32_t>> todo;   // [begin, end) ranges of `order` still to split
-    todo.push_back({0u, static_cast<uint32_t>(order.size())});
-    while (!todo.empty()) {
-        const auto [begin, end] = todo.back();
-        todo.pop_back();
+// their centroids, degenerate and non-finite primitives last.  A range is split near its middle at a
+// multiple of CLUSTER^3, CLUSTER^2 or CLUSTER (the largest it exceeds), along the axis that leaves
+// the two halves the smallest boxes (half area x count, over the primitives' own bounds), so that
+// every aligned group of CLUSTER positions is one leaf (a compact patch), every aligned group of
+// CLUSTER clusters one top node, and so on upward.  Only the box records and the triangles' pre-test
+// records are stored in this order; it decides which primitives share a box and nothing else, so
+// any permutation gives the same image.
+struct ClusterOrder {
+    const std::vector<float>& centroid;   // 3 floats per primitive
+    const std::vector<float>& bounds;     // 6 floats per primitive: low corner, high corner
+    std::vector<uint32_t> order;
+
+    static constexpr uint32_t THREAD_LEVELS = 4;        // the first levels of the tree give their left halves to a thread of their own
+    static constexpr uint32_t THREAD_MIN = 1u << 15;    // ... where a half is worth a thread
+
+    double half_area(const uint32_t* from, const uint32_t* to) const {
+        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (const uint32_t* p = from; p != to; ++p) {
+            const float* b = &bounds[static_cast<size_t>(*p) * 6];
+            for (int q = 0; q < 3; ++q) {
+                lo[q] = b[q] < lo[q] ? b[q] : lo[q];
+                hi[q] = b[3 + q] > hi[q] ? b[3 + q] : hi[q];
+            }
+        }
+        const double e[3] = {static_cast<double>(hi[0]) - lo[0], static_cast<double>(hi[1]) - lo[1], static_cast<double>(hi[2]) - lo[2]};
+        return e[0] * e[1] + e[1] * e[2] + e[0] * e[2];
+    }
+
+    // orders [begin, end) of `order`; `trial` is scratch of the calling thread
+    void split(uint32_t begin, uint32_t end, uint32_t level, std::vector<uint32_t>& trial) {
         const uint32_t count = end - begin;
-        if (count <= CLUSTER) continue;
-        const uint32_t align = count > CLUSTER * CLUSTER ? CLUSTER * CLUSTER : CLUSTER;
+        if (count <= CLUSTER) return;
+        const uint32_t align = count > CLUSTER * CLUSTER * CLUSTER ? CLUSTER * CLUSTER * CLUSTER : (count > CLUSTER * CLUSTER ? CLUSTER * CLUSTER : CLUSTER);
         uint32_t left = ((count / 2 + align / 2) / align) * align;
         if (left == 0) left = align;
         if (left >= count) left = count / 2;
-        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (uint32_t i = begin; i < end; ++i)
-            for (int q = 0; q < 3; ++q) {
-                const float v = centroid[static_cast<size_t>(order[i]) * 3 + q];
-                lo[q] = v < lo[q] ? v : lo[q]; hi[q] = v > hi[q] ? v : hi[q];
+        double best_cost = 0.0;
+        for (int axis = 0; axis < 3; ++axis) {
+            trial.assign(order.begin() + begin, order.begin() + end);
+            std::nth_element(trial.begin(), trial.begin() + left, trial.end(), [&](uint32_t x, uint32_t y) {
+                const float cx = centroid[static_cast<size_t>(x) * 3 + axis], cy = centroid[static_cast<size_t>(y) * 3 + axis];
+                return cx < cy || (cx == cy && x < y);
+            });
+            const double cost = half_area(trial.data(), trial.data() + left) * left + half_area(trial.data() + left, trial.data() + count) * (count - left);
+            if (axis == 0 || cost < best_cost) {
+                best_cost = cost;
+                std::copy(trial.begin(), trial.end(), order.begin() + begin);
             }
-        int axis = 0;
-        for (int q = 1; q < 3; ++q) if (hi[q] - lo[q] > hi[axis] - lo[axis]) axis = q;
-        std::nth_element(order.begin() + begin, order.begin() + begin + left, order.begin() + end, [&](uint32_t x, uint32_t y) {
-            const float cx = centroid[static_cast<size_t>(x) * 3 + axis], cy = centroid[static_cast<size_t>(y) * 3 + axis];
-            return cx < cy || (cx == cy && x < y);
-        });
-        todo.push_back({begin + left, end});
-        todo.push_back({begin, begin + left});
+        }
+        if (level < THREAD_LEVELS && left >= THREAD_MIN) {   // the halves are disjoint ranges of `order`
+            std::thread other([this, begin, left, level] {
+                std::vector<uint32_t> scratch;
+                split(begin, begin + left, level + 1, scratch);
+            });
+            split(begin + left, end, level + 1, trial);
+            other.join();
+        } else {
+            split(begin, begin + left, level + 1, trial);
+            split(begin + left, end, level + 1, trial);
+        }
     }
-    order.insert(order.end(), rejects.begin(), rejects.end());
-    return order;
+};
+
+std::vector<uint32_t> cluster_order(const std::vector<float>& centroid, const std::vector<float>& bounds, const std::vector<uint8_t>& good) {
+    const uint32_t n = static_cast<uint32_t>(good.size());
+    ClusterOrder work{centroid, bounds, {}};
+    std::vector<uint32_t> rejects, trial;
+    work.order.reserve(n);
+    for (uint32_t k = 0; k < n; ++k) (good[k] ? work.order : rejects).push_back(k);
+    work.split(0u, static_cast<uint32_t>(work.order.size()), 0u, trial);
+    work.order.insert(work.order.end(), rejects.begin(), rejects.end());
+    return std::move(work.order);
 }
 
 // centroids of the triangles in scan order (k = lane * batches + batch), and which of them are proper triangles
-void triangle_centroids(const float* tri8, uint32_t nb, std::vector<float>& centroid, std::vector<uint8_t>& good) {
+void triangle_centroids(const float* tri8, uint32_t nb, std::vector<float>& centroid, std::vector<float>& bounds, std::vector<uint8_t>& good) {
     const uint32_t n = 8u * nb;
     centroid.assign(static_cast<size_t>(n) * 3, 0.0f);
+    bounds.assign(static_cast<size_t>(n) * 6, 0.0f);
     good.assign(n, 0);
     for (uint32_t k = 0; k < n; ++k) {
         const uint32_t j = k / nb, i = k % nb;
@@ -2651,38 +2686,57 @@ void triangle_centroids(const float* tri8, uint32_t nb, std::vector<float>& cent
         const double c[3] = {a[0] + (ab[0] + ac[0]) / 3.0, a[1] + (ab[1] + ac[1]) / 3.0, a[2] + (ab[2] + ac[2]) / 3.0};
         const double nn = nx * nx + ny * ny + nz * nz;
         good[k] = std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(nn) && nn > 0.0;
-        if (good[k]) for (int q = 0; q < 3; ++q) centroid[static_cast<size_t>(k) * 3 + q] = static_cast<float>(c[q]);
+        if (good[k]) for (int q = 0; q < 3; ++q) {
+            centroid[static_cast<size_t>(k) * 3 + q] = static_cast<float>(c[q]);
+            bounds[static_cast<size_t>(k) * 6 + q] = static_cast<float>(a[q] + std::fmin(0.0, std::fmin(ab[q], ac[q])));
+            bounds[static_cast<size_t>(k) * 6 + 3 + q] = static_cast<float>(a[q] + std::fmax(0.0, std::fmax(ab[q], ac[q])));
+        }
     }
 }
 // centres of the ellipsoids in scan order: the translation column of the forward transform (Mat3x4x8, ray_tracing.h:62-69)
-void ellipsoid_centroids(const float* fwd8, const float* inv8, uint32_t nb, std::vector<float>& centroid, std::vector<uint8_t>& good) {
+void ellipsoid_centroids(const float* fwd8, const float* inv8, uint32_t nb, std::vector<float>& centroid, std::vector<float>& bounds, std::vector<uint8_t>& good) {
     const uint32_t n = 8u * nb;
     centroid.assign(static_cast<size_t>(n) * 3, 0.0f);
+    bounds.assign(static_cast<size_t>(n) * 6, 0.0f);
     good.assign(n, 0);
     for (uint32_t k = 0; k < n; ++k) {
         const uint32_t j = k / nb, i = k % nb;
         const float* pf = fwd8 + static_cast<size_t>(i) * 96 + j;
         const float* pi = inv8 + static_cast<size_t>(i) * 96 + j;
-        double c[3], scale = 0.0;
+        double c[3], reach[3], scale = 0.0;
         for (int row = 0; row < 3; ++row) {
             c[row] = pf[(row * 4 + 3) * 8];
-            for (int col = 0; col < 3; ++col) scale += std::fabs(static_cast<double>(pi[(row * 4 + col) * 8]));
+            double rr = 0.0;   // the image of the unit sphere reaches the length of the row along this axis
+            for (int col = 0; col < 3; ++col) {
+                scale += std::fabs(static_cast<double>(pi[(row * 4 + col) * 8]));
+                rr += static_cast<double>(pf[(row * 4 + col) * 8]) * pf[(row * 4 + col) * 8];
+            }
+            reach[row] = std::sqrt(rr);
         }
-        good[k] = std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(scale) && scale > 0.0;
-        if (good[k]) for (int q = 0; q < 3; ++q) centroid[static_cast<size_t>(k) * 3 + q] = static_cast<float>(c[q]);
+        good[k] = std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(scale) && scale > 0.0 && std::isfinite(reach[0] + reach[1] + reach[2]);
+        if (good[k]) for (int q = 0; q < 3; ++q) {
+            centroid[static_cast<size_t>(k) * 3 + q] = static_cast<float>(c[q]);
+            bounds[static_cast<size_t>(k) * 6 + q] = static_cast<float>(c[q] - reach[q]);
+            bounds[static_cast<size_t>(k) * 6 + 3 + q] = static_cast<float>(c[q] + reach[q]);
+        }
     }
 }
 
 // centres of the spheres in scan order (Sphere8: x[8], y[8], z[8], radius[8])
-void sphere_centroids(const float* sph8, uint32_t nb, std::vector<float>& centroid, std::vector<uint8_t>& good) {
+void sphere_centroids(const float* sph8, uint32_t nb, std::vector<float>& centroid, std::vector<float>& bounds, std::vector<uint8_t>& good) {
     const uint32_t n = 8u * nb;
     centroid.assign(static_cast<size_t>(n) * 3, 0.0f);
+    bounds.assign(static_cast<size_t>(n) * 6, 0.0f);
     good.assign(n, 0);
     for (uint32_t k = 0; k < n; ++k) {
         const uint32_t j = k / nb, i = k % nb;
         const float* p = sph8 + static_cast<size_t>(i) * 32 + j;
         good[k] = std::isfinite(p[0]) && std::isfinite(p[8]) && std::isfinite(p[16]) && std::isfinite(p[24]);
-        if (good[k]) for (int q = 0; q < 3; ++q) centroid[static_cast<size_t>(k) * 3 + q] = p[q * 8];
+        if (good[k]) for (int q = 0; q < 3; ++q) {
+            centroid[static_cast<size_t>(k) * 3 + q] = p[q * 8];
+            bounds[static_cast<size_t>(k) * 6 + q] = p[q * 8] - std::fabs(p[24]);
+            bounds[static_cast<size_t>(k) * 6 + 3 + q] = p[q * 8] + std::fabs(p[24]);
+        }
     }
 }
 
@@ -2799,19 +2853,19 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
         h.n_tops = ceil_div(h.n_clusters, CLUSTER);
         h.n_supers = ceil_div(h.n_tops, CLUSTER);
         if (h.n == 0) continue;
-        std::vector<float> centroid;
+        std::vector<float> centroid, bounds;
         std::vector<uint8_t> good;
         if (prim == 0) {
             if (!desc->triangle8s) return fail(rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: triangle8s is null"));
-            triangle_centroids(desc->triangle8s, d.tri_nb, centroid, good);
+            triangle_centroids(desc->triangle8s, d.tri_nb, centroid, bounds, good);
         } else if (prim == 1) {
             if (!desc->ellipsoid8_transforms || !desc->ellipsoid8_inverse_transforms) return fail(rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: ellipsoid transforms are null"));
-            ellipsoid_centroids(desc->ellipsoid8_transforms, desc->ellipsoid8_inverse_transforms, d.ell_nb, centroid, good);
+            ellipsoid_centroids(desc->ellipsoid8_transforms, desc->ellipsoid8_inverse_transforms, d.ell_nb, centroid, bounds, good);
         } else {
             if (!desc->sphere8s) return fail(rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: sphere8s is null"));
-            sphere_centroids(desc->sphere8s, d.sph_nb, centroid, good);
+            sphere_centroids(desc->sphere8s, d.sph_nb, centroid, bounds, good);
         }
-        orders[prim] = cluster_order(centroid, good);
+        orders[prim] = cluster_order(centroid, bounds, good);
         uint32_t* k_of;
         float4 *leaf_box, *cl_box, *top_box, *super_box;
         uint4 *cl_nodes, *top_nodes, *super_nodes;
