@@ -2611,20 +2611,27 @@ struct ClusterOrder {
     std::vector<uint32_t> order;
 
     static constexpr uint32_t THREAD_LEVELS = 4;        // the first levels of the tree give their left halves to a thread of their own
-    static constexpr uint32_t THREAD_MIN = 1u << 15;    // ... where a half is worth a thread
+    static constexpr uint32_t THREAD_MIN = 1u << 12;    // ... where a half is worth a thread
 
-    double half_area(const uint32_t* from, const uint32_t* to) const {
+    static constexpr int BINS = 32;
+    static constexpr uint32_t EXACT_BELOW = 4096;
+    struct Bin {
+        uint32_t count = 0;
         float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (const uint32_t* p = from; p != to; ++p) {
-            const float* b = &bounds[static_cast<size_t>(*p) * 6];
-            for (int q = 0; q < 3; ++q) {
-                lo[q] = b[q] < lo[q] ? b[q] : lo[q];
-                hi[q] = b[3 + q] > hi[q] ? b[3 + q] : hi[q];
-            }
+        void add(const float* b) {
+            ++count;
+            for (int q = 0; q < 3; ++q) { lo[q] = b[q] < lo[q] ? b[q] : lo[q]; hi[q] = b[3 + q] > hi[q] ? b[3 + q] : hi[q]; }
         }
-        const double e[3] = {static_cast<double>(hi[0]) - lo[0], static_cast<double>(hi[1]) - lo[1], static_cast<double>(hi[2]) - lo[2]};
-        return e[0] * e[1] + e[1] * e[2] + e[0] * e[2];
-    }
+        void merge(const Bin& o) {
+            count += o.count;
+            for (int q = 0; q < 3; ++q) { lo[q] = o.lo[q] < lo[q] ? o.lo[q] : lo[q]; hi[q] = o.hi[q] > hi[q] ? o.hi[q] : hi[q]; }
+        }
+        double half_area() const {
+            if (count == 0) return 0.0;
+            const double e[3] = {static_cast<double>(hi[0]) - lo[0], static_cast<double>(hi[1]) - lo[1], static_cast<double>(hi[2]) - lo[2]};
+            return e[0] * e[1] + e[1] * e[2] + e[0] * e[2];
+        }
+    };
 
     // orders [begin, end) of `order`; `trial` is scratch of the calling thread
     void split(uint32_t begin, uint32_t end, uint32_t level, std::vector<uint32_t>& trial) {
@@ -2634,18 +2641,73 @@ struct ClusterOrder {
         uint32_t left = ((count / 2 + align / 2) / align) * align;
         if (left == 0) left = align;
         if (left >= count) left = count / 2;
-        double best_cost = 0.0;
+        // Candidate planes: BINS - 1 per axis, evenly spaced over the centroids' extent.  The cost of one
+        // is half area x count of the two sides; the cheapest decides the axis and, rounded to the
+        // alignment, how many primitives go left.
+        float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (uint32_t i = begin; i < end; ++i)
+            for (int q = 0; q < 3; ++q) {
+                const float v = centroid[static_cast<size_t>(order[i]) * 3 + q];
+                clo[q] = v < clo[q] ? v : clo[q]; chi[q] = v > chi[q] ? v : chi[q];
+            }
+        int best_axis = 0;
+        for (int q = 1; q < 3; ++q) if (chi[q] - clo[q] > chi[best_axis] - clo[best_axis]) best_axis = q;
+        double best_cost = DBL_MAX;
         for (int axis = 0; axis < 3; ++axis) {
-            trial.assign(order.begin() + begin, order.begin() + end);
-            std::nth_element(trial.begin(), trial.begin() + left, trial.end(), [&](uint32_t x, uint32_t y) {
+            const double width = static_cast<double>(chi[axis]) - clo[axis];
+            if (!(width > 0.0) || !std::isfinite(width)) continue;
+            Bin bins[BINS];
+            for (uint32_t i = begin; i < end; ++i) {
+                const uint32_t k = order[i];
+                int b = static_cast<int>((static_cast<double>(centroid[static_cast<size_t>(k) * 3 + axis]) - clo[axis]) / width * BINS);
+                b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+                bins[b].add(&bounds[static_cast<size_t>(k) * 6]);
+            }
+            double right_area[BINS];
+            Bin sweep;
+            for (int b = BINS - 1; b > 0; --b) { sweep.merge(bins[b]); right_area[b] = sweep.half_area(); }
+            sweep = Bin();
+            for (int b = 1; b < BINS; ++b) {
+                sweep.merge(bins[b - 1]);
+                if (sweep.count == 0 || sweep.count == count) continue;
+                uint32_t at = ((sweep.count + align / 2) / align) * align;
+                if (at == 0) at = align;
+                if (at >= count) continue;
+                const double cost = sweep.half_area() * sweep.count + right_area[b] * (count - sweep.count);
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; left = at; }
+            }
+        }
+        if (count <= EXACT_BELOW) {
+            // small ranges: every aligned position of every axis, with the exact boxes of its two sides
+            best_cost = DBL_MAX;
+            std::vector<double> right_area(count / align + 2);
+            for (int axis = 0; axis < 3; ++axis) {
+                trial.assign(order.begin() + begin, order.begin() + end);
+                std::sort(trial.begin(), trial.end(), [&](uint32_t x, uint32_t y) {
+                    const float cx = centroid[static_cast<size_t>(x) * 3 + axis], cy = centroid[static_cast<size_t>(y) * 3 + axis];
+                    return cx < cy || (cx == cy && x < y);
+                });
+                Bin sweep;
+                for (uint32_t i = count; i-- > align;) {
+                    sweep.add(&bounds[static_cast<size_t>(trial[i]) * 6]);
+                    if (i % align == 0) right_area[i / align] = sweep.half_area();
+                }
+                sweep = Bin();
+                for (uint32_t i = 0; i + 1 < count; ++i) {
+                    sweep.add(&bounds[static_cast<size_t>(trial[i]) * 6]);
+                    const uint32_t at = i + 1;
+                    if (at % align) continue;
+                    const double cost = sweep.half_area() * at + right_area[at / align] * (count - at);
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; left = at; }
+                }
+            }
+        }
+        {
+            const int axis = best_axis;
+            std::nth_element(order.begin() + begin, order.begin() + begin + left, order.begin() + end, [&](uint32_t x, uint32_t y) {
                 const float cx = centroid[static_cast<size_t>(x) * 3 + axis], cy = centroid[static_cast<size_t>(y) * 3 + axis];
                 return cx < cy || (cx == cy && x < y);
             });
-            const double cost = half_area(trial.data(), trial.data() + left) * left + half_area(trial.data() + left, trial.data() + count) * (count - left);
-            if (axis == 0 || cost < best_cost) {
-                best_cost = cost;
-                std::copy(trial.begin(), trial.end(), order.begin() + begin);
-            }
         }
         if (level < THREAD_LEVELS && left >= THREAD_MIN) {   // the halves are disjoint ranges of `order`
             std::thread other([this, begin, left, level] {
