@@ -75,6 +75,12 @@ def main():
             raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (args.gpus, world))
         args.gpus = world
 
+    # The line of results is the only thing this program writes to its standard output: libraries that
+    # print there (RCCL announces its version on rank 0) are sent to standard error instead.
+    sys.stdout.flush()
+    results_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from raytracer_amd import abi, api, distributed
@@ -231,7 +237,8 @@ def main():
             out["frame_identical_to_single_rank_render"] = bool((alone["rgb"].reshape(-1) == frame.cpu().numpy()).all())
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(api, abi, fi, cam, scene, depth, args.cpu_crop)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(results_fd, (json.dumps(out) + "\n").encode())
 
     scene.close()
     if world > 1:
