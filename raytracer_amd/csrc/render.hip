@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -2182,6 +2183,8 @@ struct Lane {
     void* state_mem = nullptr;              // per-chunk sample state, grown on demand
     size_t state_samples = 0;
     uint32_t* counts = nullptr;             // 64 words
+    uint32_t* host_counts = nullptr;        // pinned copy of `counts`, filled word by word as the host asks (fetch_count)
+    hipEvent_t count_ready = nullptr;       // the word last asked for has arrived
 };
 struct Library {
     bool ready = false;
@@ -2296,6 +2299,7 @@ struct Timer {
     // pairs of events around launches of one kernel family; resolved after the stream is idle
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans[2];
     size_t next_event = 0;
+    std::mutex guard;   // the lanes of a frame are driven by a host thread each
     hipEvent_t take() {
         if (next_event == g_lib.events.size()) {
             hipEvent_t e;
@@ -2309,11 +2313,12 @@ struct Timer {
 template <typename Launch>
 void timed(Timer* timer, int family, hipStream_t stream, Launch&& launch) {
     if (!timer) { launch(); return; }
-    hipEvent_t a = timer->take(), b = timer->take();
+    hipEvent_t a, b;
+    { std::lock_guard<std::mutex> lock(timer->guard); a = timer->take(); b = timer->take(); }
     if (a) (void)hipEventRecord(a, stream);
     launch();
     if (b) (void)hipEventRecord(b, stream);
-    if (a && b) timer->spans[family].push_back({a, b});
+    if (a && b) { std::lock_guard<std::mutex> lock(timer->guard); timer->spans[family].push_back({a, b}); }
 }
 
 // event number i of a lane's fork/join pool
@@ -2427,7 +2432,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         HIP_TRY(hipEventRecord(g_lib.lanes_fork, g_lib.lanes[0].stream));
         for (uint32_t l = 1; l < n_lanes; ++l) HIP_TRY(hipStreamWaitEvent(g_lib.lanes[l].stream, g_lib.lanes_fork, 0));
     }
-    for (uint32_t first = 0, chunk = 0; first < my_tiles; first += chunk_tiles, ++chunk) {
+    // One chunk; every launch of it goes to the streams of its lane.
+    auto run_chunk = [&](uint32_t first, uint32_t chunk) -> int {
         Lane& lane = g_lib.lanes[chunk % n_lanes];
         const hipStream_t stream = lane.stream;       // everything of this chunk goes to its lane
         const State st = lane_state[chunk % n_lanes];
@@ -2440,12 +2446,33 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(nullptr), n_samples, st.counts, -1, static_cast<int>(ST_LIVE));
         hipLaunchKernelGGL(k_fill_list, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, st, static_cast<const uint32_t*>(nullptr), n_samples,
                            static_cast<const uint32_t*>(nullptr), st.list[0]);
-        const uint32_t scan_blocks = ceil_div(n_samples, BLOCK * RAYS_PER_LANE);
-        auto blocks_for = [&](int rays_per_lane) {   // worst-case ray blocks, and room for the split of a small launch
-            const uint32_t blocks = ceil_div(n_samples, static_cast<uint32_t>(BLOCK * rays_per_lane));
+        // The host follows the length of the chunk's ray list, one word per bounce over a pinned buffer, and
+        // sizes the grids by it: a grid sized for the chunk's capacity is mostly workgroups that find nothing
+        // to do (scene7: two thirds of the samples miss the scene box, one ray in five is reflected), and
+        // dispatching those cost a tenth of the frame.  `bound` is what the host knows: the exact length for
+        // the first bounce (one wait on an idle lane per chunk), the length of the bounce before for the
+        // others (that word arrives while the scans of the bounce before are still queued: no idle gap).
+        // A list can only shrink, so an older length is a valid bound; a chunk whose list is empty stops.
+        // (Waiting for the exact length of every bounce instead, on an idle lane each time, measured the same.)
+        uint32_t bound = n_samples;
+        auto fetch_count = [&](uint32_t b) -> int {
+            HIP_TRY(hipMemcpyAsync(lane.host_counts + b, st.counts + b, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipEventRecord(lane.count_ready, stream));
+            return 0;
+        };
+        auto wait_count = [&](uint32_t b) -> int {
+            HIP_TRY(hipEventSynchronize(lane.count_ready));
+            bound = std::min(bound, lane.host_counts[b]);
+            return 0;
+        };
+        if (int rc = fetch_count(0)) return rc;
+        if (int rc = wait_count(0)) return rc;
+        auto ray_blocks = [&] { return ceil_div(std::max(bound, 1u), BLOCK); };
+        auto scan_blocks = [&] { return ceil_div(std::max(bound, 1u), BLOCK * RAYS_PER_LANE); };
+        auto blocks_for = [&](int rays_per_lane) {   // ray blocks, and room for the split of a small launch
+            const uint32_t blocks = ceil_div(std::max(bound, 1u), static_cast<uint32_t>(BLOCK * rays_per_lane));
             return blocks > SEG_TARGET ? blocks : SEG_TARGET;
         };
-        const uint32_t ray_blocks = n_samples / BLOCK;
         // state as bounce b sees it: the two ray sets swap roles every bounce
         auto state_of = [&](uint32_t b) {
             State sb = st;
@@ -2474,15 +2501,15 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
             };
             timed(timer, 0, on, [&] {
                 if (sc.n_tri) {
-                    if (!walk[0]) hipLaunchKernelGGL((k_closest_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
+                    if (!walk[0]) hipLaunchKernelGGL((k_closest_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b);
                     else hierarchy_scan(0);
                 }
                 if (sc.n_sph) {
-                    if (!walk[2]) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
+                    if (!walk[2]) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b);
                     else hierarchy_scan(2);
                 }
                 if (sc.n_ell) {
-                    if (!walk[1]) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks), dim3(BLOCK), 0, on, sc, sb, b);
+                    if (!walk[1]) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b);
                     else hierarchy_scan(1);
                 }
             });
@@ -2500,15 +2527,16 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         // shadow scans + k_shade.  The closest-hit scans of bounce b+1 need only the reflected rays and the
         // list, so they run on the side stream beside the shadow scans of bounce b (their tails overlap);
         // k_hit of bounce b+1 waits for both.
-        if (depth) closest_scans(0, stream);
-        for (uint32_t b = 0; b < depth; ++b) {
+        if (depth && bound) closest_scans(0, stream);
+        for (uint32_t b = 0; b < depth && bound; ++b) {
             const State sb = state_of(b);
-            hipLaunchKernelGGL(k_hit, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, sb, b);
+            hipLaunchKernelGGL(k_hit, dim3(ray_blocks()), dim3(BLOCK), 0, stream, sc, sb, b);
             hipLaunchKernelGGL(k_scan_flags, dim3(scan_grid), dim3(SCAN_THREADS), 0, stream, sb, static_cast<const uint32_t*>(sb.counts + b), 0u);
             hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_THREADS), 0, stream, sb, static_cast<const uint32_t*>(sb.counts + b), 0u, sb.counts + b + 1,
                                static_cast<int>(ST_CLOSEST_RAYS), static_cast<int>(ST_HITS));
-            hipLaunchKernelGGL(k_fill_list, dim3(ray_blocks), dim3(BLOCK), 0, stream, sb, static_cast<const uint32_t*>(sb.counts + b), 0u,
+            hipLaunchKernelGGL(k_fill_list, dim3(ray_blocks()), dim3(BLOCK), 0, stream, sb, static_cast<const uint32_t*>(sb.counts + b), 0u,
                                static_cast<const uint32_t*>(sb.list[b & 1u]), sb.list[(b + 1) & 1u]);
+            if (int rc = fetch_count(b + 1)) return rc;
             const bool overlap = filter && b + 1 < depth;   // brute force is timed launch by launch: no overlap there
             hipEvent_t forked = overlap ? sync_event(lane, 2 * b) : nullptr, joined = overlap ? sync_event(lane, 2 * b + 1) : nullptr;
             if (overlap && forked && joined) {
@@ -2518,7 +2546,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                 HIP_TRY(hipEventRecord(joined, lane.side_stream));
             }
             if (sc.n_lights == 0) {
-                hipLaunchKernelGGL(k_shade, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, sb, b, 0u, 0u, 1u);
+                hipLaunchKernelGGL(k_shade, dim3(ray_blocks()), dim3(BLOCK), 0, stream, sc, sb, b, 0u, 0u, 1u);
             } else {
                 for (uint32_t l0 = 0; l0 < sc.n_lights; l0 += 32) {
                     const uint32_t group = (sc.n_lights - l0 < 32) ? sc.n_lights - l0 : 32;
@@ -2527,7 +2555,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                     const uint32_t n_pt = group - n_dir;
                     // brute-force shadow scan of one kind toward lights first.. (n of them)
                     auto brute_force = [&](int prim, uint32_t n, uint32_t first_light) {
-                        const dim3 grid(scan_blocks, n);
+                        const dim3 grid(scan_blocks(), n);
                         if (prim == 0) hipLaunchKernelGGL((k_shadow_scan<RAYS_PER_LANE, 0, 0>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                         else if (prim == 1) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                         else hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
@@ -2547,16 +2575,40 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                             }
                         }
                     });
-                    hipLaunchKernelGGL(k_shade, dim3(ray_blocks), dim3(BLOCK), 0, stream, sc, sb, b, l0, group, (l0 + group == sc.n_lights) ? 1u : 0u);
+                    hipLaunchKernelGGL(k_shade, dim3(ray_blocks()), dim3(BLOCK), 0, stream, sc, sb, b, l0, group, (l0 + group == sc.n_lights) ? 1u : 0u);
                 }
             }
             if (overlap && forked && joined) HIP_TRY(hipStreamWaitEvent(stream, joined, 0));
             else if (b + 1 < depth) closest_scans(b + 1, stream);
+            if (b + 1 < depth) if (int rc = wait_count(b + 1)) return rc;
         }
         hipLaunchKernelGGL(k_resolve, dim3(n_tiles), dim3(BLOCK), 0, stream, st, first, tiles_dev);
         if (ids_dev) hipLaunchKernelGGL(k_scatter_ids, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, st.primary_id, first, n_samples, f, ids_dev);
         HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    // Chunk c belongs to lane c % n_lanes.  A lane waits for its own counts, so each is driven by a host
+    // thread of its own: the caller's thread takes lane 0.
+    const uint32_t n_chunks = ceil_div(my_tiles, chunk_tiles);
+    auto run_lane = [&](uint32_t l) -> int {
+        for (uint32_t chunk = l; chunk < n_chunks; chunk += n_lanes)
+            if (int rc = run_chunk(chunk * chunk_tiles, chunk)) return rc;
+        return 0;
+    };
+    int lane_rc[MAX_LANES] = {};
+    std::string lane_error[MAX_LANES];
+    {
+        std::vector<std::thread> helpers;
+        for (uint32_t l = 1; l < n_lanes; ++l)
+            helpers.emplace_back([&, l] {
+                lane_rc[l] = hipSetDevice(g_lib.device) == hipSuccess ? run_lane(l) : rt_fail(RT_ERR_DEVICE, "hipSetDevice failed in the thread of a lane");
+                if (lane_rc[l]) lane_error[l] = g_last_error;   // the message is per thread
+            });
+        lane_rc[0] = run_lane(0);
+        for (std::thread& t : helpers) t.join();
     }
+    if (lane_rc[0]) return lane_rc[0];
+    for (uint32_t l = 1; l < n_lanes; ++l) if (lane_rc[l]) return rt_fail(lane_rc[l], lane_error[l].c_str());
     for (uint32_t l = 1; l < n_lanes; ++l) {
         HIP_TRY(hipEventRecord(g_lib.lanes_join[l], g_lib.lanes[l].stream));
         HIP_TRY(hipStreamWaitEvent(stream, g_lib.lanes_join[l], 0));
@@ -2838,6 +2890,8 @@ int rt_init(int device) {
         HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&lane.side_stream, hipStreamNonBlocking));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&lane.counts), 64 * sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&lane.host_counts), 64 * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&lane.count_ready, hipEventDisableTiming));
     }
     g_lib.stream = g_lib.lanes[0].stream;
     HIP_TRY(hipEventCreateWithFlags(&g_lib.lanes_fork, hipEventDisableTiming));
