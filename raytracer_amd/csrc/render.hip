@@ -1095,8 +1095,11 @@ constexpr uint32_t QCAP = RT_QCAP, PUSH_MAX = 256;
 #ifndef RT_STAGE_RAYS
 #define RT_STAGE_RAYS(R, LEVELS) ((LEVELS) == 3)
 #endif
+// The walking scans ask for at least 5 waves per SIMD, i.e. at most 96 VGPRs: left alone the shadow scans
+// take 97 to 109, which the allocation granule of 8 turns into 4 waves (1 M-triangle scene: 423 -> 399 ms;
+// the LDS of a workgroup, 27 to 32 KB, allows 5 workgroups per CU as well).  Brute force is left alone.
 #ifndef RT_SCAN_ATTR
-#define RT_SCAN_ATTR
+#define RT_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(LEVELS ? 5 : 1)))
 #endif
 constexpr uint32_t NODE_MASK = 0xFFFFFFu;
 // For every set bit b < n_bits of a lane's `bits`, append base + b*step.  Entries of one bit are contiguous, in lane order.
