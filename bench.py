@@ -27,8 +27,8 @@ TILE_BYTES = 768
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="scene7_4k")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
