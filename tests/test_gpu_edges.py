@@ -139,3 +139,13 @@ def test_eye_far_outside_the_scene_box_and_back(gpu, oracle, tmp_path):
         results.append(g)
     scene.close()
     assert np.array_equal(results[0]["rgb"], results[2]["rgb"]) and results[1]["stats"].hits > 0
+
+
+def test_coincident_and_collinear_primitives(gpu, oracle, tmp_path):
+    # the host ordering finds no extent to split along (all centroids equal), or only one axis (a row of spheres)
+    text = HEADER.format(w=48, h=32, depth=3, cam="0 2 9 0 0 0") + FLOOR
+    text += "tri 0 2 1\n" * 300 + "sphere 0.5 0.2 0.3 0.7\n" * 200
+    text += "".join("sphere %g 1.5 -1 0.05\n" % (-3 + 0.02 * i) for i in range(300))
+    text += "pushTransform\ntranslate -1 0.5 1\nscale 0.5 0.3 0.2\n" + "sphere 0 0 0 1\n" * 150 + "popTransform\n"
+    o = compare(gpu, oracle, write(tmp_path, "coincident", text))
+    assert o["stats"].hits > 0
