@@ -36,6 +36,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk-tiles", type=int, default=0, help="tiles per chunk of ray state (0 = library default)")
     ap.add_argument("--brute-force", action="store_true", help="RT_FLAG_NO_FILTER: every ray-primitive pair through the literal full test")
+    ap.add_argument("--plain-test", action="store_true", help="with --brute-force: RT_FLAG_PLAIN_TEST, the triangle test exactly as written (three IEEE divisions per pair)")
     ap.add_argument("--cpu-crop", default="240x135", help="centred crop the CPU baseline renders (WxH)")
     return ap.parse_args()
 
@@ -107,6 +108,8 @@ def main():
     scene = api.Scene(fi.scene_desc)     # upload, re-packing on the GPU, bounding hierarchy (kd ordering on the host)
     scene_create_s = time.perf_counter() - t_setup
     flags = abi.RT_FLAG_NO_FILTER if args.brute_force else 0
+    if args.plain_test:
+        flags |= abi.RT_FLAG_PLAIN_TEST
     prm = fi.params(max_bounce_count=depth, tile_rank=rank, tile_world=world, flags=flags, chunk_tiles=args.chunk_tiles)
     stride = distributed.stride_tiles(prm, world)      # tiles per rank in the gathered buffer
     assert api.rank_tile_count(prm) == len(distributed.rank_tiles(prm, rank, world)) <= stride

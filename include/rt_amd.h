@@ -99,6 +99,8 @@ typedef struct rt_render_params {
 #define RT_FLAG_NO_FILTER 1u      /* run every ray-primitive test through the full test; no bounding hierarchy, no conservative pre-test */
 #define RT_FLAG_WALK_ALL  2u      /* walk the bounding hierarchy of every primitive kind, also of kinds so small that the
                                      library would scan them by brute force (same results; for tests and tuning) */
+#define RT_FLAG_PLAIN_TEST 8u     /* brute-force triangle scans evaluate the test exactly as written (three IEEE divisions per pair) instead of
+                                     in stages that skip what the outcome does not depend on (same results; for measurements) */
 #define RT_FLAG_DEEP_WALK 4u      /* walk every hierarchy the way the library walks big ones (from the super nodes, two rays
                                      per lane) whatever its size (same results; for tests and tuning) */
 

@@ -93,6 +93,7 @@ RT_SAMPLES_PER_PIXEL = 16
 RT_FLAG_NO_FILTER = 1
 RT_FLAG_WALK_ALL = 2
 RT_FLAG_DEEP_WALK = 4
+RT_FLAG_PLAIN_TEST = 8
 RT_ID_MISS = 0xFFFFFFFF
 RT_ID_CULLED = 0xFFFFFFFE
 

@@ -100,7 +100,7 @@ struct Hierarchy {
 };
 
 struct DevScene {
-    const float4* tri;   // 4 x float4 per triangle: (a, n.x) (a_to_b, n.y) (a_to_c, n.z) (n.n, 0, 0, 0)
+    const float4* tri;   // 4 x float4 per triangle: (a, n.x) (a_to_b, n.y) (a_to_c, n.z) (n.n, RN(1/n.n) or NaN, 0, 0)
     const float4* trif;  // pre-test records, 4 x float4 per triangle, see pretest_stage1
     const float4* trif_pos;  // the same in cluster order (th.k_of), with the scan index in the spare word [2].w
     Hierarchy th;        // bounding records of the triangles, see Hierarchy
@@ -281,6 +281,69 @@ DEV float hit_triangle(V3 o, V3 d, float4 t0, float4 t1, float4 t2, float nn) {
     const float beta = vdot(vcross(ap, ac), n) / nn;
     const bool outside = (alpha < 0.0f) | (beta < 0.0f) | (alpha + beta > 1.0f);
     return (parallel | behind | outside) ? FLT_MAX : t;
+}
+
+// The same test evaluated in stages, for the brute-force scans, where almost every pair misses and
+// the three IEEE divisions are the largest single cost of the test as written above (13 issue slots
+// each on gfx950).  The result is that of hit_triangle bit for bit; the stages only avoid computing
+// what the outcome does not depend on.
+//   tri_front: d.n and (a-o).n exactly as hit_triangle computes them.  A lane whose |d.n| is below
+//              the tolerance is "parallel"; a lane whose two dot products differ in sign has a
+//              quotient t <= -0, which is "behind".  Either way the result is FLT_MAX.
+//   tri_head:  t by the IEEE division, the hit point, and alpha's numerator x1 = (ab x ap).n, all
+//              exactly as in hit_triangle.  alpha itself, RN(x1 / nn), is only ever compared:
+//              a1 = x1 * y with y = RN(1/nn) from the record is within 2^-22 (relative) of it, so
+//              a1 < -TINY implies alpha < 0, and a1 > 1 + BAND implies alpha > 1, which rejects
+//              the pair whatever beta is (beta < 0 rejects; beta >= 0 makes alpha + beta > 1).
+//   tri_tail:  beta's numerator and b1 = x2 * y likewise: b1 < -TINY implies beta < 0,
+//              a1 + b1 > 1 + BAND implies alpha + beta > 1, and a1, b1 > TINY with
+//              a1 + b1 < 1 - BAND implies the pair is accepted with distance t.  Anything else
+//              (a quotient within TINY of zero, a sum within BAND of one) is "unsure": the caller
+//              then runs hit_triangle itself.
+// The argument needs every intermediate to be finite, so that no comparison meets a NaN that
+// hit_triangle would meet differently: the record holds y = NaN (every comparison false, hence
+// unsure) unless |a|, |a_to_b|, |a_to_c| <= TAME_COORD per component and nn is within
+// [2^-60, 2^60], and the scans take this path only for rays with |o| <= TAME_COORD and
+// |d| <= 2 per component (ray_is_tame).  Then for a lane that is not parallel |t| < 2^54,
+// |ap| < 2^56 and both numerators stay below 2^96.
+constexpr float BARY_TINY = 1.0e-30f;
+constexpr float BARY_BAND = 9.5367431640625e-7f;   // 2^-20
+constexpr float TAME_COORD = 4096.0f;
+DEV bool ray_is_tame(V3 o, V3 d) {
+    return fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))) <= TAME_COORD && fmaxf(fabsf(d.x), fmaxf(fabsf(d.y), fabsf(d.z))) <= 2.0f;
+}
+// Decisions that concern the whole wave are taken on lane masks (one bit per lane, in scalar registers).
+using Mask = unsigned long long;
+DEV Mask ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+struct TriFront { float dn, num; };
+DEV TriFront tri_front(V3 o, V3 d, float4 t0, float4 t1, float4 t2, Mask& out) {
+    const V3 n{t0.w, t1.w, t2.w};
+    TriFront f;
+    f.dn = vdot(d, n);
+    f.num = vdot(sub(xyz(t0), o), n);
+    out = ballot(__builtin_fabsf(f.dn) < TOL) | ballot(static_cast<int>(__float_as_uint(f.dn) ^ __float_as_uint(f.num)) < 0);
+    return f;
+}
+struct TriHead { float t, a1; V3 ap; };
+DEV TriHead tri_head(V3 o, V3 d, const TriFront& f, float4 t0, float4 t1, float4 t2, float y, Mask& out) {
+    const V3 n{t0.w, t1.w, t2.w};
+    TriHead h;
+    h.t = f.num / f.dn;
+    const V3 p = add(o, scale(h.t, d));
+    h.ap = sub(p, xyz(t0));
+    h.a1 = vdot(vcross(xyz(t1), h.ap), n) * y;
+    out |= ballot(h.t < TOL) | ballot(h.a1 < -BARY_TINY) | ballot(h.a1 > 1.0f + BARY_BAND);
+    return h;
+}
+// `out`: this lane is among those the earlier stages rejected
+DEV float tri_tail(const TriHead& h, bool out, float4 t0, float4 t1, float4 t2, float y, bool& unsure) {
+    const V3 n{t0.w, t1.w, t2.w};
+    const float b1 = vdot(vcross(h.ap, xyz(t2)), n) * y;
+    const float sum = h.a1 + b1;
+    out = out | (b1 < -BARY_TINY) | (sum > 1.0f + BARY_BAND);
+    const bool in = (h.a1 > BARY_TINY) & (b1 > BARY_TINY) & (sum < 1.0f - BARY_BAND);
+    unsure = !(out | in);
+    return out ? FLT_MAX : h.t;
 }
 
 // Conservative pre-test of one ray against one triangle, in two stages.  A stage returns
@@ -567,7 +630,11 @@ __global__ void __launch_bounds__(BLOCK) k_prep_triangles(const float* __restric
     o[0] = make_float4(a.x, a.y, a.z, n.x);
     o[1] = make_float4(ab.x, ab.y, ab.z, n.y);
     o[2] = make_float4(ac.x, ac.y, ac.z, n.z);
-    o[3] = make_float4(nn, 0.0f, 0.0f, 0.0f);
+    // y = RN(1/nn) for the staged form of the test (tri_head), NaN where that form is not proven
+    const float coord_max = fmaxf(fmaxf(fabsf(a.x), fmaxf(fabsf(a.y), fabsf(a.z))),
+                                  fmaxf(fmaxf(fabsf(ab.x), fmaxf(fabsf(ab.y), fabsf(ab.z))), fmaxf(fabsf(ac.x), fmaxf(fabsf(ac.y), fabsf(ac.z)))));
+    const bool regular = coord_max <= TAME_COORD && nn >= 8.673617379884035e-19f && nn <= 1.152921504606847e18f;   // 2^-60, 2^60
+    o[3] = make_float4(nn, regular ? 1.0f / nn : __builtin_nanf(""), 0.0f, 0.0f);
     // pre-test record (pretest_stage1): nothing here has to match the reference's rounding
     const float inv_nn = 1.0f / nn;
     const V3 w1 = scale(inv_nn, vcross(n, ab));
@@ -1099,7 +1166,7 @@ constexpr uint32_t QCAP = RT_QCAP, PUSH_MAX = 256;
 // take 97 to 109, which the allocation granule of 8 turns into 4 waves (1 M-triangle scene: 423 -> 399 ms;
 // the LDS of a workgroup, 27 to 32 KB, allows 5 workgroups per CU as well).  Brute force is left alone.
 #ifndef RT_SCAN_ATTR
-#define RT_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(LEVELS ? 5 : 1)))
+#define RT_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(5)))
 #endif
 constexpr uint32_t NODE_MASK = 0xFFFFFFu;
 // For every set bit b < n_bits of a lane's `bits`, append base + b*step.  Entries of one bit are contiguous, in lane order.
@@ -1131,73 +1198,100 @@ DEV float pretests_then_full(const DevScene& sc, const TriPair& f, V3 o, V3 d, u
     return hit_triangle(o, d, rec[0], rec[1], rec[2], rec[3].x);
 }
 
-// Closest hit of every live ray over the primitives of kind PRIM (0 triangles, 1 ellipsoids, 2 spheres).
-// WALK = false: brute force, every triangle through the full test (RT_FLAG_NO_FILTER, small
-// scenes): tiles of records staged in LDS, broadcast reads, per-lane running minimum.
-// WALK = true: the wave walks the box hierarchy of the kind.  Top nodes are tested one per lane
+// Brute force over the triangle list (RT_FLAG_NO_FILTER, and lists too short for a hierarchy): every
+// ray of the workgroup against every triangle.  Tiles of TILE_PRIMS records are staged in LDS and read
+// back as broadcasts (every lane of a wave reads the same record), R rays per lane share each read.
+// STAGED: the test is evaluated in stages (tri_front / tri_head / tri_tail) and a stage is skipped
+// when no lane of the wave needs it; otherwise every pair goes through hit_triangle as written
+// (RT_FLAG_PLAIN_TEST, and waves that hold a ray outside the range the staged form is proven for).
+// `limit[r]`: a result counts only below it (FLT_MAX for closest-hit rays, the light's distance for
+// shadow rays toward a point light).  visit(r, k, t) is called, for all lanes of the wave at once,
+// when some lane may have a result for ray r; lanes without one see FLT_MAX.
+template <int R, bool STAGED, typename Visit>
+DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, const V3 (&o)[R], const V3 (&d)[R], bool staged_wave, Visit&& visit) {
+    if (STAGED && staged_wave) {
+        const Mask everyone = ballot(true);
+        const uint32_t lane = threadIdx.x & 63u;
+        for (uint32_t k = 0; k < count; ++k) {
+            const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
+            TriFront front[R];
+            Mask out[R], in_play = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { front[r] = tri_front(o[r], d[r], t0, t1, t2, out[r]); in_play |= everyone & ~out[r]; }
+            if (in_play == 0) continue;
+            TriHead head[R];
+            in_play = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { head[r] = tri_head(o[r], d[r], front[r], t0, t1, t2, t3.y, out[r]); in_play |= everyone & ~out[r]; }
+            if (in_play == 0) continue;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                bool unsure;
+                float t = tri_tail(head[r], ((out[r] >> lane) & 1ull) != 0ull, t0, t1, t2, t3.y, unsure);
+                if (__any(unsure)) t = hit_triangle(o[r], d[r], t0, t1, t2, t3.x);
+                visit(r, first + k, t);
+            }
+        }
+    } else {
+#pragma unroll 2
+        for (uint32_t k = 0; k < count; ++k) {
+            const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
+#pragma unroll
+            for (int r = 0; r < R; ++r) visit(r, first + k, hit_triangle(o[r], d[r], t0, t1, t2, t3.x));
+        }
+    }
+}
+
+template <int R, bool STAGED>
+__global__ void __launch_bounds__(BLOCK) k_closest_tri_brute(DevScene sc, State st, uint32_t bounce) {
+    __shared__ float4 lds[TILE_PRIMS * 4];
+    const uint32_t n_rays = st.counts[bounce];
+    const uint32_t base = blockIdx.x * (BLOCK * R);
+    if (base >= n_rays) return;
+    uint32_t slot[R];
+    bool valid[R];
+    V3 o[R], d[R];
+    load_rays<R>(st, st.list[bounce & 1u], base, n_rays, slot, valid, o, d);
+    float best_t[R]; uint32_t best_k[R];
+    bool tame = true;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { best_t[r] = FLT_MAX; best_k[r] = 0xFFFFFFFFu; tame = tame && ray_is_tame(o[r], d[r]); }
+    const bool staged_wave = __all(tame);
+    for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
+        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
+        __syncthreads();
+        stage_tile<4>(lds, sc.tri, first, count);
+        __syncthreads();
+        brute_force_tile<R, STAGED>(lds, first, count, o, d, staged_wave, [&](int r, uint32_t k, float t) __attribute__((always_inline)) {
+            if (t < best_t[r]) { best_t[r] = t; best_k[r] = k; }
+        });
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) if (valid[r]) st.key[slot[r]] = best_k[r] == 0xFFFFFFFFu ? NO_HIT_KEY : pack_hit(best_t[r], best_k[r]);
+}
+
+// Closest hit of every live ray over the primitives of kind PRIM (0 triangles, 1 ellipsoids, 2 spheres):
+// the wave walks the box hierarchy of the kind.  Top nodes are tested one per lane
 // against the bound of the whole wave (packet test), then per ray; (ray, node) pairs go through
 // three per-wave queues in LDS (top node -> cluster -> leaf), each walked one pair per lane, and
 // the (ray, leaf) pairs that remain through the full test of the kind (for triangles after the
 // two-stage pre-test).  Result: st.key[slot] / st.key_ell[slot] / st.key_sph[slot], by atomicMin.
 template <int R, int LEVELS, int PRIM>
 __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc, State st, uint32_t bounce) {
-    static_assert(LEVELS == 0 || LEVELS == 3 || LEVELS == 4, "brute force, or a walk from the top nodes or from the super nodes");
-    constexpr bool WALK = LEVELS != 0;
-    constexpr int N_QUEUES = WALK ? LEVELS : 3;
-    static_assert(WALK || PRIM == 0, "the full-test mode of this kernel is for triangles");
+    static_assert(LEVELS == 3 || LEVELS == 4, "a walk from the top nodes or from the super nodes");
+    constexpr int N_QUEUES = LEVELS;
     static_assert(64 * R <= PUSH_MAX && 64 * R <= 256, "a queue entry has 8 bits for the ray, a push adds at most PUSH_MAX entries");
     const Hierarchy& h = PRIM == 0 ? sc.th : (PRIM == 1 ? sc.eh : sc.sh);
-    constexpr int WORDS = 4;
-    __shared__ float4 lds[WALK ? 1 : TILE_PRIMS * WORDS];   // record tiles, full-test mode only
     constexpr uint32_t WAVE_LDS = N_QUEUES * QCAP + 64 * R;   // per wave: one queue per level ((ray, top node), (ray, cluster), (ray, leaf), with LEVELS = 4 also (ray, super node)), slot table
-    __shared__ uint32_t lds_queue[WALK ? (BLOCK / 64) * WAVE_LDS : 1];
+    __shared__ uint32_t lds_queue[(BLOCK / 64) * WAVE_LDS];
     // the wave's rays, staged once for the lanes that walk their pairs: (o, growth) (d, -) (1/d, -) per ray
-    constexpr bool STAGED = WALK && RT_STAGE_RAYS(R, LEVELS);
+    constexpr bool STAGED = RT_STAGE_RAYS(R, LEVELS);
     __shared__ float4 lds_rays[STAGED ? (BLOCK / 64) * 64 * R * 3 : 1];
     const uint32_t n_rays = st.counts[bounce];
     const uint32_t* __restrict__ list_in = st.list[bounce & 1u];
-    ScanSplit split;
-    if (!WALK) {
-        split = ScanSplit{blockIdx.x * (BLOCK * R), 0u, sc.n_tri, blockIdx.x * (BLOCK * R) < n_rays};
-    } else {
-        split = scan_split(n_rays, BLOCK * R, LEVELS == 4 ? h.n_supers : h.n_tops, LEVELS == 4 ? 1u : 16u);
-    }
+    const ScanSplit split = scan_split(n_rays, BLOCK * R, LEVELS == 4 ? h.n_supers : h.n_tops, LEVELS == 4 ? 1u : 16u);
     if (!split.active) return;
     const uint32_t base = split.ray_base;
-
-    if (!WALK) {
-        uint32_t slot[R];
-        bool valid[R];
-        V3 o[R], d[R];
-        float best_t[R]; uint32_t best_k[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t i = base + r * BLOCK + threadIdx.x;
-            valid[r] = i < n_rays;
-            slot[r] = list_in[valid[r] ? i : base];
-            o[r] = {st.ox[slot[r]], st.oy[slot[r]], st.oz[slot[r]]};
-            d[r] = {st.dx[slot[r]], st.dy[slot[r]], st.dz[slot[r]]};
-            best_t[r] = FLT_MAX; best_k[r] = 0xFFFFFFFFu;
-        }
-        for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
-            const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
-            __syncthreads();
-            stage_tile<4>(lds, sc.tri, first, count);
-            __syncthreads();
-#pragma unroll 2
-            for (uint32_t k = 0; k < count; ++k) {
-                const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float t = hit_triangle(o[r], d[r], t0, t1, t2, t3.x);
-                    if (t < best_t[r]) { best_t[r] = t; best_k[r] = first + k; }
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) if (valid[r]) st.key[slot[r]] = best_k[r] == 0xFFFFFFFFu ? NO_HIT_KEY : pack_hit(best_t[r], best_k[r]);
-        return;
-    }
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t* const q0 = lds_queue + wave * WAVE_LDS;      // (ray, top node)
@@ -1731,33 +1825,57 @@ DEV ShadowRay make_shadow_ray(const State& st, uint32_t slot, bool point, V3 lv)
     return s;
 }
 
-// Any-hit of every hit point toward light first_light + blockIdx.y over the primitives of kind PRIM.
-// WALK = false: brute force over the triangles.  WALK = true: the box hierarchy of the kind, queues
+// Brute-force any-hit over the triangle list toward light first_light + blockIdx.y (see k_closest_tri_brute).
+template <int R, bool STAGED>
+__global__ void __launch_bounds__(BLOCK) k_shadow_tri_brute(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
+    __shared__ float4 lds[TILE_PRIMS * 4];
+    const uint32_t n_rays = st.counts[bounce + 1];
+    const uint32_t base = blockIdx.x * (BLOCK * R);
+    if (base >= n_rays) return;
+    const float* __restrict__ L = sc.lights + (first_light + blockIdx.y) * 8;
+    const uint32_t light_bit = 1u << (first_light + blockIdx.y - group_first);
+    ShadowRays<R> s;
+    load_shadow_rays<R>(st, st.list[(bounce + 1) & 1u], base, n_rays, L[0] != 0.0f, V3{L[1], L[2], L[3]}, light_bit, s);
+    bool tame = true;
+#pragma unroll
+    for (int r = 0; r < R; ++r) tame = tame && ray_is_tame(s.o[r], s.d[r]);
+    const bool staged_wave = __all(tame);
+    unsigned long long wave_tests = 0;
+    bool done = shadow_wave_done<R>(s);
+    for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
+        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
+        if (__syncthreads_and(done)) break;
+        stage_tile<4>(lds, sc.tri, first, count);
+        __syncthreads();
+        if (!done) {
+            wave_tests += shadow_live_tests<R>(s, count);
+            brute_force_tile<R, STAGED>(lds, first, count, s.o, s.d, staged_wave, [&](int r, uint32_t, float t) __attribute__((always_inline)) {
+                s.blocked[r] |= t < s.limit[r];
+            });
+            done = shadow_wave_done<R>(s);
+        }
+    }
+    store_shadow_result<R>(st, s, light_bit, stat_slot(st, ST_SHADOW_TESTS_TRI), wave_tests);
+}
+
+// Any-hit of every hit point toward light first_light + blockIdx.y over the primitives of kind PRIM:
+// the box hierarchy of the kind, queues
 // as in k_closest_scan; a (ray, leaf) pair that blocks sets the ray's bit in LDS, which the lane
 // that holds the ray picks up after the drain; the wave stops when all its rays are blocked.
 template <int R, int LEVELS, int PRIM>
 __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
-    static_assert(LEVELS == 0 || LEVELS == 3 || LEVELS == 4, "brute force, or a walk from the top nodes or from the super nodes");
-    constexpr bool WALK = LEVELS != 0;
-    constexpr int N_QUEUES = WALK ? LEVELS : 3;
-    static_assert(WALK || PRIM == 0, "the full-test mode of this kernel is for triangles");
+    static_assert(LEVELS == 3 || LEVELS == 4, "a walk from the top nodes or from the super nodes");
+    constexpr int N_QUEUES = LEVELS;
     static_assert(64 * R <= PUSH_MAX && 64 * R <= 256, "a queue entry has 8 bits for the ray, a push adds at most PUSH_MAX entries");
     const Hierarchy& h = PRIM == 0 ? sc.th : (PRIM == 1 ? sc.eh : sc.sh);
-    constexpr int WORDS = 4;
-    __shared__ float4 lds[WALK ? 1 : TILE_PRIMS * WORDS];   // record tiles, full-test mode only
     constexpr uint32_t WAVE_LDS = N_QUEUES * QCAP + 64 * R;   // per wave: one queue per level ((ray, top node), (ray, cluster), (ray, leaf), with LEVELS = 4 also (ray, super node)), slot table
-    __shared__ uint32_t lds_queue[WALK ? (BLOCK / 64) * WAVE_LDS : 1];
+    __shared__ uint32_t lds_queue[(BLOCK / 64) * WAVE_LDS];
     __shared__ uint32_t lds_blocked[BLOCK];   // bit r: ray r of that thread is blocked (set by drains)
     // the wave's shadow rays, staged once for the lanes that walk their pairs: (o, limit) (d, -) (1/d, limit of the box test) per ray
-    constexpr bool STAGED = WALK && RT_STAGE_RAYS(R, LEVELS);
+    constexpr bool STAGED = RT_STAGE_RAYS(R, LEVELS);
     __shared__ float4 lds_rays[STAGED ? (BLOCK / 64) * 64 * R * 3 : 1];
     const uint32_t n_rays = st.counts[bounce + 1];
-    ScanSplit split;
-    if (!WALK) {
-        split = ScanSplit{blockIdx.x * (BLOCK * R), 0u, sc.n_tri, blockIdx.x * (BLOCK * R) < n_rays};
-    } else {
-        split = scan_split(n_rays, BLOCK * R, LEVELS == 4 ? h.n_supers : h.n_tops, LEVELS == 4 ? 1u : 16u);
-    }
+    const ScanSplit split = scan_split(n_rays, BLOCK * R, LEVELS == 4 ? h.n_supers : h.n_tops, LEVELS == 4 ? 1u : 16u);
     if (!split.active) return;
     const uint32_t base = split.ray_base;
     const uint32_t* __restrict__ list_in = st.list[(bounce + 1) & 1u];
@@ -1797,19 +1915,13 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             unsafe |= !(fmaxf(fabsf(s.o.x), fmaxf(fabsf(s.o.y), fabsf(s.o.z))) <= sc.box_bound);
             if (!point) unsafe |= !(vdot(s.d, s.d) <= SPH_DIR_CHECK);   // a directional light's direction is the caller's: the pre-tests and the spheres' boxes need unit length
             blocked[r] = (st.blocked[slot[r]] & light_bit) != 0u;
-            if (WALK) lds_queue[(threadIdx.x >> 6) * WAVE_LDS + N_QUEUES * QCAP + r * 64 + (threadIdx.x & 63u)] = slot[r];
+            lds_queue[(threadIdx.x >> 6) * WAVE_LDS + N_QUEUES * QCAP + r * 64 + (threadIdx.x & 63u)] = slot[r];
         }
-        if (WALK) packet = uniform_packet(make_packet<R>(d, o, valid));
+        packet = uniform_packet(make_packet<R>(d, o, valid));
     }
     lds_blocked[threadIdx.x] = 0u;
     wave_sync();
-    const bool keep_all = WALK && __any(unsafe);
-    auto wave_done = [&]() {
-        bool all = true;
-#pragma unroll
-        for (int r = 0; r < R; ++r) all = all && (blocked[r] || !valid[r]);
-        return __all(all) != 0;
-    };
+    const bool keep_all = __any(unsafe);
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t* const q0 = lds_queue + wave * WAVE_LDS;      // (ray, top node)
@@ -1925,34 +2037,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     auto drain_first = [&]() __attribute__((always_inline)) { if constexpr (LEVELS == 4) drain_supers(); else drain0(); };
 
     unsigned long long wave_tests = 0;   // tests spent on still-undecided rays (wave-uniform)
-    bool done = wave_done();
-    const float4* __restrict__ tri_stream = sc.tri;   // full-test mode
-    if (!WALK) {
-        for (uint32_t first = split.first_prim; first < split.end_prim; first += TILE_PRIMS) {
-            const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), split.end_prim - first);
-            if (__syncthreads_and(done)) break;
-            stage_tile<WORDS>(lds, tri_stream, first, count);
-            __syncthreads();
-            if (!done) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) wave_tests += static_cast<unsigned long long>(count) * __popcll(__ballot(valid[r] && !blocked[r]));
-                V3 o[R];
-                float limit[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const ShadowRay s = make_shadow_ray(st, slot[r], point, lv);
-                    o[r] = s.o; limit[r] = s.limit;
-                }
-#pragma unroll 2
-                for (uint32_t k = 0; k < count; ++k) {
-                    const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) blocked[r] |= hit_triangle(o[r], d[r], t0, t1, t2, t3.x) < limit[r];
-                }
-                done = wave_done();
-            }
-        }
-    } else {
+    {
         auto live_rays = [&]() {
             uint32_t n = 0;
 #pragma unroll
@@ -1988,10 +2073,10 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     for (int r = 0; r < R; ++r)
         if (valid[r] && blocked[r]) atomicOr(&st.blocked[slot[r]], light_bit);
     if ((threadIdx.x & 63u) == 0 && wave_tests) atomicAdd(stat_slot(st, PRIM == 0 ? ST_SHADOW_TESTS_TRI : (PRIM == 1 ? ST_SHADOW_TESTS_ELL : ST_SHADOW_TESTS_SPH)), wave_tests);
-    if (WALK && PRIM == 0) block_add_stat(stat_slot(st, ST_FULL_TESTS), n_full);
+    if (PRIM == 0) block_add_stat(stat_slot(st, ST_FULL_TESTS), n_full);
     if ((threadIdx.x & 63u) == 0 && n_pairs) atomicAdd(stat_slot(st, ST_PAIR_PRETESTS_SHADOW), n_pairs);
     if ((threadIdx.x & 63u) == 0 && n_queued) atomicAdd(stat_slot(st, ST_QUEUED_SHADOW), static_cast<unsigned long long>(n_queued));
-    if (WALK) {   // FLOP executed in per-ray tests (n_full is per lane; the others are wave totals)
+    {   // FLOP executed in per-ray tests (n_full is per lane; the others are wave totals)
         constexpr unsigned long long CHILD = 24, LEAF = PRIM == 0 ? 40 : (PRIM == 1 ? 71 : 19), FULL = PRIM == 0 ? 54 : 0;
         block_add_stat(stat_slot(st, ST_FLOP_SHADOW), FULL * n_full + ((threadIdx.x & 63u) == 0 ? CHILD * n_pairs + LEAF * n_queued : 0ull));
     }
@@ -2428,6 +2513,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
 
     const uint32_t depth = static_cast<uint32_t>(prm->max_bounce_count);
     const bool filter = (prm->flags & RT_FLAG_NO_FILTER) == 0;
+    const bool plain_test = (prm->flags & RT_FLAG_PLAIN_TEST) != 0;
     // per kind (0 triangles, 1 ellipsoids, 2 spheres): walk its hierarchy, or scan it by brute force
     const uint32_t below = (prm->flags & RT_FLAG_WALK_ALL) ? 0u : brute_force_below();
     const bool force_deep = (prm->flags & RT_FLAG_DEEP_WALK) != 0;
@@ -2518,8 +2604,9 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
             };
             timed(timer, 0, on, [&] {
                 if (sc.n_tri) {
-                    if (!walk[0]) hipLaunchKernelGGL((k_closest_scan<RAYS_PER_LANE, 0, 0>), dim3(scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b);
-                    else hierarchy_scan(0);
+                    if (walk[0]) hierarchy_scan(0);
+                    else if (plain_test) hipLaunchKernelGGL((k_closest_tri_brute<RAYS_PER_LANE, false>), dim3(scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b);
+                    else hipLaunchKernelGGL((k_closest_tri_brute<RAYS_PER_LANE, true>), dim3(scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b);
                 }
                 if (sc.n_sph) {
                     if (!walk[2]) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b);
@@ -2573,7 +2660,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                     // brute-force shadow scan of one kind toward lights first.. (n of them)
                     auto brute_force = [&](int prim, uint32_t n, uint32_t first_light) {
                         const dim3 grid(scan_blocks(), n);
-                        if (prim == 0) hipLaunchKernelGGL((k_shadow_scan<RAYS_PER_LANE, 0, 0>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
+                        if (prim == 0 && plain_test) hipLaunchKernelGGL((k_shadow_tri_brute<RAYS_PER_LANE, false>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
+                        else if (prim == 0) hipLaunchKernelGGL((k_shadow_tri_brute<RAYS_PER_LANE, true>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                         else if (prim == 1) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                         else hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                     };
