@@ -203,6 +203,31 @@ int rt_render_file_info(const rt_file_info* info, uint8_t* rgb_out, rt_stats* st
  * pixel-identical, not byte-identical). */
 int rt_write_png(const char* filename, uint32_t width, uint32_t height, const uint8_t* rgb);
 
+/* ---- test hook -----------------------------------------------------------------
+ * Evaluates ONE device routine of the render loop on n items, so that the GPU forms of the
+ * reference's scalar and AVX routines can be compared bit for bit with known answers
+ * (maths.cpp:9-159 fp_pow / fp_min / fp_max; ray_tracing.cpp:460-473, :265-297, :129-165, :169-206).
+ * All pointers are host memory.  Layout per operation (floats):
+ *   FP_POW, FP_MIN, FP_MAX, DIVIDE, DIVIDE_IN_RANGE: a[n], b[n] -> out[n]
+ *   PRIMARY_RAY: a = eye, basis i, j, k, half_world w h, half width and half height in pixels (16);
+ *                b = pixel x, pixel y, x offset, y offset per item -> out = direction (3 per item)
+ *   SCENE_BOX:   a = min_x max_x min_y max_y min_z max_z; b = origin, direction per item -> out = min, max distance
+ *   TRIANGLE, TRIANGLE_STAGED: a = a, a_to_b, a_to_c per item (9); b = origin, direction per item -> out[n]
+ *                (distance or FLT_MAX; STAGED evaluates the staged form the brute-force scans use and reports
+ *                NaN where that form declares itself unsure and the scans fall back to the plain form)
+ *   SPHERE:      a = centre, radius per item (4); b = origin, direction per item -> out[n] */
+#define RT_DEBUG_FP_POW 0
+#define RT_DEBUG_FP_MIN 1
+#define RT_DEBUG_FP_MAX 2
+#define RT_DEBUG_DIVIDE 3
+#define RT_DEBUG_DIVIDE_IN_RANGE 4
+#define RT_DEBUG_PRIMARY_RAY 5
+#define RT_DEBUG_SCENE_BOX 6
+#define RT_DEBUG_TRIANGLE 7
+#define RT_DEBUG_TRIANGLE_STAGED 8
+#define RT_DEBUG_SPHERE 9
+int rt_debug_eval(int op, uint32_t n, const float* a, const float* b, float* out);
+
 #ifdef __cplusplus
 }
 #endif

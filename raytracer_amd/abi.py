@@ -94,6 +94,8 @@ RT_FLAG_NO_FILTER = 1
 RT_FLAG_WALK_ALL = 2
 RT_FLAG_DEEP_WALK = 4
 RT_FLAG_PLAIN_TEST = 8
+(RT_DEBUG_FP_POW, RT_DEBUG_FP_MIN, RT_DEBUG_FP_MAX, RT_DEBUG_DIVIDE, RT_DEBUG_DIVIDE_IN_RANGE, RT_DEBUG_PRIMARY_RAY,
+ RT_DEBUG_SCENE_BOX, RT_DEBUG_TRIANGLE, RT_DEBUG_TRIANGLE_STAGED, RT_DEBUG_SPHERE) = range(10)
 RT_ID_MISS = 0xFFFFFFFF
 RT_ID_CULLED = 0xFFFFFFFE
 
@@ -121,6 +123,7 @@ PROTOTYPES = {
     "rt_camera_setup": (None, [C.POINTER(C.c_float * 11), C.POINTER(CameraDesc)]),
     "rt_render_file_info": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "rt_write_png": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "rt_debug_eval": (C.c_int, [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 

@@ -156,3 +156,13 @@ def assemble_tiles_device(gathered_ptr, tiles_per_rank_stride, params, rgb_ptr):
 def write_png(filename, rgb):
     rgb = np.ascontiguousarray(rgb, np.uint8)
     _check(lib().rt_write_png(os.fsencode(filename), rgb.shape[1], rgb.shape[0], rgb.ctypes.data))
+
+
+def debug_eval(op, a, b, out_per_item, n=None):
+    """rt_debug_eval: one device routine on n items; a, b are float32 arrays laid out as include/rt_amd.h says."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    n = len(b) if n is None else n
+    out = np.zeros(n * out_per_item, np.float32)
+    _check(lib().rt_debug_eval(int(op), n, a.ctypes.data, b.ctypes.data, out.ctypes.data))
+    return out

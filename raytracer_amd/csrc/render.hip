@@ -324,15 +324,42 @@ DEV TriFront tri_front(V3 o, V3 d, float4 t0, float4 t1, float4 t2, Mask& out) {
     out = ballot(__builtin_fabsf(f.dn) < TOL) | ballot(static_cast<int>(__float_as_uint(f.dn) ^ __float_as_uint(f.num)) < 0);
     return f;
 }
+// The same for rays that all start at one point (rays from the eye): (a-o).n is then a property of
+// the triangle, computed once per tile by tile_shared_numerators with the very expression above.
+// Triangles behind such rays are rare, so the sign test is left to tri_head's t < tolerance.
+DEV TriFront tri_front_shared(V3 d, float4 t0, float4 t1, float4 t2, float num, Mask& out) {
+    const V3 n{t0.w, t1.w, t2.w};
+    TriFront f;
+    f.dn = vdot(d, n);
+    f.num = num;
+    out = ballot(__builtin_fabsf(f.dn) < TOL);
+    return f;
+}
+// num / den, correctly rounded, for the operands tri_head can meet on a lane that is still in play:
+// |den| in [1e-4, 2^28], |num| < 2^41, signs equal.  This is the instruction sequence the compiler
+// emits for an IEEE division (reciprocal, one Newton step on it, quotient, two residual corrections)
+// without its range scaling (v_div_scale) and special-case fix-up (v_div_fixup), which do nothing
+// for |num| >= 2^-100 here.  Below that the quotient is below 2^-86 either way, i.e. far under the
+// tolerance it is compared with next, and its exact bits reach nothing else.
+DEV float divide_in_range(float num, float den) {
+    const float y0 = __builtin_amdgcn_rcpf(den);
+    const float e = fma_(-den, y0, 1.0f);
+    const float y1 = fma_(e, y0, y0);
+    const float q0 = num * y1;
+    const float r0 = fma_(-den, q0, num);
+    const float q1 = fma_(r0, y1, q0);
+    const float r1 = fma_(-den, q1, num);
+    return fma_(r1, y1, q1);
+}
 struct TriHead { float t, a1; V3 ap; };
 DEV TriHead tri_head(V3 o, V3 d, const TriFront& f, float4 t0, float4 t1, float4 t2, float y, Mask& out) {
     const V3 n{t0.w, t1.w, t2.w};
     TriHead h;
-    h.t = f.num / f.dn;
+    h.t = divide_in_range(f.num, f.dn);
     const V3 p = add(o, scale(h.t, d));
     h.ap = sub(p, xyz(t0));
     h.a1 = vdot(vcross(xyz(t1), h.ap), n) * y;
-    out |= ballot(h.t < TOL) | ballot(h.a1 < -BARY_TINY) | ballot(h.a1 > 1.0f + BARY_BAND);
+    out |= ballot(!(h.t >= TOL)) | ballot(h.a1 < -BARY_TINY) | ballot(h.a1 > 1.0f + BARY_BAND);
     return h;
 }
 // `out`: this lane is among those the earlier stages rejected
@@ -618,23 +645,30 @@ DEV void block_add_stat(unsigned long long* stat, unsigned long long value) {
 // ------------------------------------------------------------------------------------------
 // scene preparation: reference AoSoA-8 -> scan-ordered records
 // ------------------------------------------------------------------------------------------
+// Full-test record of one triangle: (a, n.x) (a_to_b, n.y) (a_to_c, n.z) (n.n, y, 0, 0) with n = a_to_b x a_to_c
+// and n.n as ray_tracing.cpp:131,148 compute them, and y = RN(1/n.n) for the staged form of the test
+// (tri_head), NaN where that form is not proven.
+DEV void make_tri_record(V3 a, V3 ab, V3 ac, float4* o) {
+    const V3 n = vcross(ab, ac);
+    const float nn = vdot(n, n);
+    o[0] = make_float4(a.x, a.y, a.z, n.x);
+    o[1] = make_float4(ab.x, ab.y, ab.z, n.y);
+    o[2] = make_float4(ac.x, ac.y, ac.z, n.z);
+    const float coord_max = fmaxf(fmaxf(fabsf(a.x), fmaxf(fabsf(a.y), fabsf(a.z))),
+                                  fmaxf(fmaxf(fabsf(ab.x), fmaxf(fabsf(ab.y), fabsf(ab.z))), fmaxf(fabsf(ac.x), fmaxf(fabsf(ac.y), fabsf(ac.z)))));
+    const bool regular = coord_max <= TAME_COORD && nn >= 8.673617379884035e-19f && nn <= 1.152921504606847e18f;   // 2^-60, 2^60
+    o[3] = make_float4(nn, regular ? 1.0f / nn : __builtin_nanf(""), 0.0f, 0.0f);
+}
 __global__ void __launch_bounds__(BLOCK) k_prep_triangles(const float* __restrict__ tri8, uint32_t nb, float4* __restrict__ out, float4* __restrict__ outf) {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= 8u * nb) return;
     const uint32_t j = k / nb, i = k % nb;
     const float* p = tri8 + static_cast<size_t>(i) * 72 + j;
     const V3 a{p[0], p[8], p[16]}, ab{p[24], p[32], p[40]}, ac{p[48], p[56], p[64]};
-    const V3 n = vcross(ab, ac);
-    const float nn = vdot(n, n);
     float4* o = out + static_cast<size_t>(k) * 4;
-    o[0] = make_float4(a.x, a.y, a.z, n.x);
-    o[1] = make_float4(ab.x, ab.y, ab.z, n.y);
-    o[2] = make_float4(ac.x, ac.y, ac.z, n.z);
-    // y = RN(1/nn) for the staged form of the test (tri_head), NaN where that form is not proven
-    const float coord_max = fmaxf(fmaxf(fabsf(a.x), fmaxf(fabsf(a.y), fabsf(a.z))),
-                                  fmaxf(fmaxf(fabsf(ab.x), fmaxf(fabsf(ab.y), fabsf(ab.z))), fmaxf(fabsf(ac.x), fmaxf(fabsf(ac.y), fabsf(ac.z)))));
-    const bool regular = coord_max <= TAME_COORD && nn >= 8.673617379884035e-19f && nn <= 1.152921504606847e18f;   // 2^-60, 2^60
-    o[3] = make_float4(nn, regular ? 1.0f / nn : __builtin_nanf(""), 0.0f, 0.0f);
+    make_tri_record(a, ab, ac, o);
+    const V3 n{o[0].w, o[1].w, o[2].w};
+    const float nn = o[3].x;
     // pre-test record (pretest_stage1): nothing here has to match the reference's rounding
     const float inv_nn = 1.0f / nn;
     const V3 w1 = scale(inv_nn, vcross(n, ab));
@@ -954,6 +988,28 @@ __global__ void __launch_bounds__(BLOCK) k_prep_ellipsoid_lights(const float4* _
 DEV uint32_t tile_pixel_x(uint32_t q) { return (q & 1u) | ((q >> 1) & 2u) | ((q >> 2) & 4u) | ((q >> 3) & 8u); }
 DEV uint32_t tile_pixel_y(uint32_t q) { return ((q >> 1) & 1u) | ((q >> 2) & 2u) | ((q >> 3) & 4u) | ((q >> 4) & 8u); }
 
+// ray_tracing.cpp:460-473
+DEV V3 primary_direction(const Frame& f, uint32_t x, uint32_t y, float xo, float yo) {
+    const float alpha = f.hw[0] * (f.half_w_px - (static_cast<float>(x) + xo)) / f.half_w_px;
+    const float beta = f.hw[1] * (f.half_h_px - (static_cast<float>(y) + yo)) / f.half_h_px;
+    const V3 bi{f.bi[0], f.bi[1], f.bi[2]}, bj{f.bj[0], f.bj[1], f.bj[2]}, bk{f.bk[0], f.bk[1], f.bk[2]};
+    return normalise(add(add(scale(alpha, bi), scale(beta, bj)), bk));
+}
+// ray_tracing.cpp:271-294; bb = min_x max_x min_y max_y min_z max_z
+DEV void scene_box_distances(V3 o, V3 d, const float* bb, float& min_distance, float& max_distance) {
+    const float ix = 1.0f / d.x;
+    const float x0 = (bb[0] - o.x) * ix, x1 = (bb[1] - o.x) * ix;
+    const float min_x = fp_min(x0, x1), max_x = fp_max(x0, x1);
+    const float iy = 1.0f / d.y;
+    const float y0 = (bb[2] - o.y) * iy, y1 = (bb[3] - o.y) * iy;
+    const float min_y = fp_min(y0, y1), max_y = fp_max(y0, y1);
+    const float iz = 1.0f / d.z;
+    const float z0 = (bb[4] - o.z) * iz, z1 = (bb[5] - o.z) * iz;
+    const float min_z = fp_min(z0, z1), max_z = fp_max(z0, z1);
+    min_distance = fp_max(min_z, fp_max(min_y, min_x));
+    max_distance = fp_min(max_z, fp_min(max_y, max_x));
+}
+
 // ------------------------------------------------------------------------------------------
 // k_primary: one thread per sample of the chunk
 // ------------------------------------------------------------------------------------------
@@ -971,25 +1027,10 @@ __global__ void __launch_bounds__(BLOCK) k_primary(Frame f, DevScene sc, State s
     // render_work_queue.cpp:40-41: offsets 2.0, 2.25, 2.5, 2.75 (exact in binary32)
     const float xo = static_cast<float>(sample % 4u) * 0.25f + 2.0f;
     const float yo = static_cast<float>(sample / 4u) * 0.25f + 2.0f;
-    // ray_tracing.cpp:469-472
-    const float alpha = f.hw[0] * (f.half_w_px - (static_cast<float>(x) + xo)) / f.half_w_px;
-    const float beta = f.hw[1] * (f.half_h_px - (static_cast<float>(y) + yo)) / f.half_h_px;
-    const V3 bi{f.bi[0], f.bi[1], f.bi[2]}, bj{f.bj[0], f.bj[1], f.bj[2]}, bk{f.bk[0], f.bk[1], f.bk[2]};
-    const V3 d = normalise(add(add(scale(alpha, bi), scale(beta, bj)), bk));
+    const V3 d = primary_direction(f, x, y, xo, yo);
     const V3 o{f.eye[0], f.eye[1], f.eye[2]};
-
-    // ray_tracing.cpp:271-294
-    const float ix = 1.0f / d.x;
-    const float x0 = (sc.bb[0] - o.x) * ix, x1 = (sc.bb[1] - o.x) * ix;
-    const float min_x = fp_min(x0, x1), max_x = fp_max(x0, x1);
-    const float iy = 1.0f / d.y;
-    const float y0 = (sc.bb[2] - o.y) * iy, y1 = (sc.bb[3] - o.y) * iy;
-    const float min_y = fp_min(y0, y1), max_y = fp_max(y0, y1);
-    const float iz = 1.0f / d.z;
-    const float z0 = (sc.bb[4] - o.z) * iz, z1 = (sc.bb[5] - o.z) * iz;
-    const float min_z = fp_min(z0, z1), max_z = fp_max(z0, z1);
-    const float min_distance = fp_max(min_z, fp_max(min_y, min_x));
-    const float max_distance = fp_min(max_z, fp_min(max_y, max_x));
+    float min_distance, max_distance;
+    scene_box_distances(o, d, sc.bb, min_distance, max_distance);
     const bool live = inside && (max_distance >= min_distance);   // render_work_queue.cpp:46
 
     st.cr[s] = 0.0f; st.cg[s] = 0.0f; st.cb[s] = 0.0f;
@@ -1207,7 +1248,7 @@ DEV float pretests_then_full(const DevScene& sc, const TriPair& f, V3 o, V3 d, u
 // `limit[r]`: a result counts only below it (FLT_MAX for closest-hit rays, the light's distance for
 // shadow rays toward a point light).  visit(r, k, t) is called, for all lanes of the wave at once,
 // when some lane may have a result for ray r; lanes without one see FLT_MAX.
-template <int R, bool STAGED, typename Visit>
+template <int R, bool STAGED, bool SHARED, typename Visit>
 DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, const V3 (&o)[R], const V3 (&d)[R], bool staged_wave, Visit&& visit) {
     if (STAGED && staged_wave) {
         const Mask everyone = ballot(true);
@@ -1217,7 +1258,10 @@ DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, con
             TriFront front[R];
             Mask out[R], in_play = 0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { front[r] = tri_front(o[r], d[r], t0, t1, t2, out[r]); in_play |= everyone & ~out[r]; }
+            for (int r = 0; r < R; ++r) {
+                front[r] = SHARED ? tri_front_shared(d[r], t0, t1, t2, t3.z, out[r]) : tri_front(o[r], d[r], t0, t1, t2, out[r]);
+                in_play |= everyone & ~out[r];
+            }
             if (in_play == 0) continue;
             TriHead head[R];
             in_play = 0;
@@ -1232,6 +1276,13 @@ DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, con
                 visit(r, first + k, t);
             }
         }
+    } else if constexpr (STAGED) {   // a wave with a ray outside the staged form's range: rare, kept small
+#pragma nounroll
+        for (uint32_t k = 0; k < count; ++k) {
+            const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
+#pragma unroll
+            for (int r = 0; r < R; ++r) visit(r, first + k, hit_triangle(o[r], d[r], t0, t1, t2, t3.x));
+        }
     } else {
 #pragma unroll 2
         for (uint32_t k = 0; k < count; ++k) {
@@ -1239,6 +1290,14 @@ DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, con
 #pragma unroll
             for (int r = 0; r < R; ++r) visit(r, first + k, hit_triangle(o[r], d[r], t0, t1, t2, t3.x));
         }
+    }
+}
+// (a-o).n of every triangle of the staged tile for the origin o all rays of the workgroup share, into the
+// record's spare word [3].z; one triangle per thread, between two barriers of the caller.
+DEV void tile_shared_numerators(float4* lds, uint32_t count, V3 o) {
+    if (threadIdx.x < count) {
+        const float4 t0 = lds[threadIdx.x * 4], t1 = lds[threadIdx.x * 4 + 1], t2 = lds[threadIdx.x * 4 + 2];
+        reinterpret_cast<float*>(lds + threadIdx.x * 4 + 3)[2] = vdot(sub(xyz(t0), o), V3{t0.w, t1.w, t2.w});
     }
 }
 
@@ -1257,14 +1316,33 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri_brute(DevScene sc, State 
 #pragma unroll
     for (int r = 0; r < R; ++r) { best_t[r] = FLT_MAX; best_k[r] = 0xFFFFFFFFu; tame = tame && ray_is_tame(o[r], d[r]); }
     const bool staged_wave = __all(tame);
+    // rays from the eye share their origin: then (a-o).n is computed once per triangle and tile, not once per pair
+    bool same = true;
+#pragma unroll
+    for (int r = 0; r < R; ++r) same = same && o[r].x == o[0].x && o[r].y == o[0].y && o[r].z == o[0].z;
+    const V3 o_first{__shfl(o[0].x, 0), __shfl(o[0].y, 0), __shfl(o[0].z, 0)};
+    same = same && o[0].x == o_first.x && o[0].y == o_first.y && o[0].z == o_first.z;
+    __shared__ float lds_origin[3];
+    if (threadIdx.x == 0) { lds_origin[0] = o[0].x; lds_origin[1] = o[0].y; lds_origin[2] = o[0].z; }
+    __syncthreads();
+    const V3 o_block{lds_origin[0], lds_origin[1], lds_origin[2]};
+    same = same && o[0].x == o_block.x && o[0].y == o_block.y && o[0].z == o_block.z;
+    const bool shared_origin = STAGED && __syncthreads_and(same && tame);
+    auto visit = [&](int r, uint32_t k, float t) __attribute__((always_inline)) {
+        if (t < best_t[r]) { best_t[r] = t; best_k[r] = k; }
+    };
     for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
         __syncthreads();
         stage_tile<4>(lds, sc.tri, first, count);
         __syncthreads();
-        brute_force_tile<R, STAGED>(lds, first, count, o, d, staged_wave, [&](int r, uint32_t k, float t) __attribute__((always_inline)) {
-            if (t < best_t[r]) { best_t[r] = t; best_k[r] = k; }
-        });
+        if (shared_origin) {
+            tile_shared_numerators(lds, count, o_block);
+            __syncthreads();
+            brute_force_tile<R, STAGED, true>(lds, first, count, o, d, staged_wave, visit);
+        } else {
+            brute_force_tile<R, STAGED, false>(lds, first, count, o, d, staged_wave, visit);
+        }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) if (valid[r]) st.key[slot[r]] = best_k[r] == 0xFFFFFFFFu ? NO_HIT_KEY : pack_hit(best_t[r], best_k[r]);
@@ -1849,7 +1927,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri_brute(DevScene sc, State s
         __syncthreads();
         if (!done) {
             wave_tests += shadow_live_tests<R>(s, count);
-            brute_force_tile<R, STAGED>(lds, first, count, s.o, s.d, staged_wave, [&](int r, uint32_t, float t) __attribute__((always_inline)) {
+            brute_force_tile<R, STAGED, false>(lds, first, count, s.o, s.d, staged_wave, [&](int r, uint32_t, float t) __attribute__((always_inline)) {
                 s.blocked[r] |= t < s.limit[r];
             });
             done = shadow_wave_done<R>(s);
@@ -2253,6 +2331,60 @@ __global__ void __launch_bounds__(BLOCK) k_scatter_ids(const uint32_t* __restric
     const uint32_t rx = (tile % f.tiles_x) * RT_TILE + tile_pixel_x(pixel);
     const uint32_t ry = (tile / f.tiles_x) * RT_TILE + tile_pixel_y(pixel);
     if (rx < f.rect_w && ry < f.rect_h) out[(static_cast<size_t>(ry) * f.rect_w + rx) * RT_SAMPLES_PER_PIXEL + sample] = chunk_ids[s];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_debug_eval: the device routines one at a time, for known-answer tests (rt_debug_eval)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_debug_eval(int op, uint32_t n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t j = i < n ? i : 0u;          // lanes past the end repeat item 0 and store nothing (wave-wide ballots need every lane)
+    const bool store = i < n;
+    switch (op) {
+    case RT_DEBUG_FP_POW: { const float v = fp_pow(a[j], b[j]); if (store) out[j] = v; break; }
+    case RT_DEBUG_FP_MIN: { const float v = fp_min(a[j], b[j]); if (store) out[j] = v; break; }
+    case RT_DEBUG_FP_MAX: { const float v = fp_max(a[j], b[j]); if (store) out[j] = v; break; }
+    case RT_DEBUG_DIVIDE: { const float v = a[j] / b[j]; if (store) out[j] = v; break; }
+    case RT_DEBUG_DIVIDE_IN_RANGE: { const float v = divide_in_range(a[j], b[j]); if (store) out[j] = v; break; }
+    case RT_DEBUG_PRIMARY_RAY: {   // a: eye, i, j, k, half_world (14), half_w_px, half_h_px; b: x, y, x offset, y offset per item
+        Frame f;
+        for (int q = 0; q < 3; ++q) { f.eye[q] = a[q]; f.bi[q] = a[3 + q]; f.bj[q] = a[6 + q]; f.bk[q] = a[9 + q]; }
+        f.hw[0] = a[12]; f.hw[1] = a[13]; f.half_w_px = a[14]; f.half_h_px = a[15];
+        const V3 d = primary_direction(f, static_cast<uint32_t>(b[j * 4]), static_cast<uint32_t>(b[j * 4 + 1]), b[j * 4 + 2], b[j * 4 + 3]);
+        if (store) { out[j * 3] = d.x; out[j * 3 + 1] = d.y; out[j * 3 + 2] = d.z; }
+        break;
+    }
+    case RT_DEBUG_SCENE_BOX: {     // a: box (6); b: origin, direction per item
+        float lo, hi;
+        scene_box_distances(V3{b[j * 6], b[j * 6 + 1], b[j * 6 + 2]}, V3{b[j * 6 + 3], b[j * 6 + 4], b[j * 6 + 5]}, a, lo, hi);
+        if (store) { out[j * 2] = lo; out[j * 2 + 1] = hi; }
+        break;
+    }
+    case RT_DEBUG_TRIANGLE:
+    case RT_DEBUG_TRIANGLE_STAGED: {   // a: a, a_to_b, a_to_c per item (9); b: origin, direction per item
+        float4 rec[4];
+        make_tri_record(V3{a[j * 9], a[j * 9 + 1], a[j * 9 + 2]}, V3{a[j * 9 + 3], a[j * 9 + 4], a[j * 9 + 5]}, V3{a[j * 9 + 6], a[j * 9 + 7], a[j * 9 + 8]}, rec);
+        const V3 o{b[j * 6], b[j * 6 + 1], b[j * 6 + 2]}, d{b[j * 6 + 3], b[j * 6 + 4], b[j * 6 + 5]};
+        float t = hit_triangle(o, d, rec[0], rec[1], rec[2], rec[3].x);
+        if (op == RT_DEBUG_TRIANGLE_STAGED && ray_is_tame(o, d)) {
+            Mask out_mask;
+            const TriFront front = tri_front(o, d, rec[0], rec[1], rec[2], out_mask);
+            const TriHead head = tri_head(o, d, front, rec[0], rec[1], rec[2], rec[3].y, out_mask);
+            bool unsure;
+            const float staged = tri_tail(head, ((out_mask >> (threadIdx.x & 63u)) & 1ull) != 0ull, rec[0], rec[1], rec[2], rec[3].y, unsure);
+            // an unsure pair reports NaN: the scans run the plain form for it, and the test counts such pairs
+            t = unsure ? __builtin_nanf("") : staged;
+        }
+        if (store) out[j] = t;
+        break;
+    }
+    case RT_DEBUG_SPHERE: {        // a: centre, radius per item (4); b: origin, direction per item
+        const float t = hit_sphere(V3{b[j * 6], b[j * 6 + 1], b[j * 6 + 2]}, V3{b[j * 6 + 3], b[j * 6 + 4], b[j * 6 + 5]}, make_float4(a[j * 4], a[j * 4 + 1], a[j * 4 + 2], a[j * 4 + 3]));
+        if (store) out[j] = t;
+        break;
+    }
+    default: break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3215,6 +3347,33 @@ int rt_render_file_info(const rt_file_info* info, uint8_t* rgb_out, rt_stats* st
     p.width = info->width; p.height = info->height; p.max_bounce_count = info->max_recursion_depth;
     rc = rt_render(scene, &cam, &p, rgb_out, nullptr, stats);
     rt_scene_destroy(scene);
+    return rc;
+}
+
+int rt_debug_eval(int op, uint32_t n, const float* a, const float* b, float* out) {
+    if (!g_lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    static const struct { int op; uint32_t a_per_item, a_fixed, b_per_item, out_per_item; } shapes[] = {
+        {RT_DEBUG_FP_POW, 1, 0, 1, 1}, {RT_DEBUG_FP_MIN, 1, 0, 1, 1}, {RT_DEBUG_FP_MAX, 1, 0, 1, 1}, {RT_DEBUG_DIVIDE, 1, 0, 1, 1},
+        {RT_DEBUG_DIVIDE_IN_RANGE, 1, 0, 1, 1}, {RT_DEBUG_PRIMARY_RAY, 0, 16, 4, 3}, {RT_DEBUG_SCENE_BOX, 0, 6, 6, 2},
+        {RT_DEBUG_TRIANGLE, 9, 0, 6, 1}, {RT_DEBUG_TRIANGLE_STAGED, 9, 0, 6, 1}, {RT_DEBUG_SPHERE, 4, 0, 6, 1}};
+    const auto* shape = &shapes[0];
+    bool found = false;
+    for (const auto& sh : shapes) if (sh.op == op) { shape = &sh; found = true; }
+    if (!found) return rt_fail(RT_ERR_ARGUMENT, "rt_debug_eval: unknown operation");
+    if (!a || !b || !out || n == 0 || n > (1u << 26)) return rt_fail(RT_ERR_ARGUMENT, "rt_debug_eval: null argument or item count out of range");
+    const size_t na = static_cast<size_t>(shape->a_per_item) * n + shape->a_fixed, nb = static_cast<size_t>(shape->b_per_item) * n, no = static_cast<size_t>(shape->out_per_item) * n;
+    float* dev = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), (na + nb + no) * sizeof(float)));
+    int rc = 0;
+    hipStream_t stream = g_lib.stream;
+    if (hipMemcpyAsync(dev, a, na * sizeof(float), hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(dev + na, b, nb * sizeof(float), hipMemcpyHostToDevice, stream) != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_debug_eval: upload failed");
+    if (rc == 0) {
+        hipLaunchKernelGGL(k_debug_eval, dim3(ceil_div(n, BLOCK)), dim3(BLOCK), 0, stream, op, n, static_cast<const float*>(dev), static_cast<const float*>(dev + na), dev + na + nb);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, dev + na + nb, no * sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_debug_eval: kernel or copy back failed");
+    }
+    (void)hipFree(dev);
     return rc;
 }
 
