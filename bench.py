@@ -2,14 +2,20 @@
 """Benchmark of the render loop: one step = one full frame of the workload, image tiles split
 over the ranks (one process per GPU), framebuffer assembled on rank 0 from an RCCL all-gather.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload scene7_4k|scene1|...|synthetic]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload synthetic|scene7_4k|scene1|...]
 
-Prints one JSON line on rank 0: metric, value, unit, n_gpus, steps, warmup, ms_per_step, ..., `roofline` (closest-hit
-scan kernels against the FP32 vector peak) and `cpu_baseline` (the CPU renderer on a crop of the same frame).  For N > 1 launch with
+Default workload: the largest configuration, the synthetic scene (1 M triangles + 10 k ellipsoids, 8 point lights,
+3840x2160, maxdepth 2).  Prints one JSON line on rank 0:
+* `value` = ray segments per second of the timed frames (default mode of the library: bounding hierarchy + exact tests);
+* `roofline` = a BRUTE-FORCE leg on a centred crop of the same frame (RT_FLAG_NO_FILTER: every ray against every primitive,
+  launches one after the other on one stream): ray-triangle pairs x 54 FLOP / HIP-event time of the closest-hit triangle
+  scan launches, against the FP32 vector peak; the shadow scan beside it;
+* `culled_mode` = what the default mode executed (box tests, pre-tests, full tests) during the timed frames;
+* `cpu_baseline` = the CPU renderer on a small crop of the same frame (N = 1 only).
+For N > 1 launch with
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -22,22 +28,30 @@ sys.path.insert(0, ROOT)
 FLOP_TRI, FLOP_SPH, FLOP_ELL_CLOSEST, FLOP_ELL_SHADOW_POINT, FLOP_ELL_SHADOW_DIR = 54, 19, 95, 71, 62
 PEAK_FP32_TFLOPS = 157.3   # MI355X FP32 vector peak: 256 CU x 4 SIMD x 32 lanes x 2 FLOP x 2.4 GHz
 TILE_BYTES = 768
+# centred crops (WxH): the brute-force leg, and the CPU baseline (sized for 10-30 s of CPU work on 16 threads)
+BRUTE_CROP = {"synthetic": "512x288", "default": "512x288"}
+CPU_CROP = {"synthetic": "48x27", "default": "240x135"}
+# how the generated scene departs from a plain reading of its specification (raytracer_amd/synth.py)
+SYNTHETIC_NOTES = ("seeded numpy PCG64 streams (triangles seed 1, ellipsoids 2, materials 3); light colour .15 and diffuse/specular U[0.1,0.5] "
+                   "so that no channel reaches 1.0 with 8 lights (the reference's 8-bit conversion is undefined above); lights on a ring of radius 25 at height 8")
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="scene7_4k")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="synthetic")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--maxdepth", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-brute-force-leg", action="store_true")
     ap.add_argument("--chunk-tiles", type=int, default=0, help="tiles per chunk of ray state (0 = library default)")
-    ap.add_argument("--brute-force", action="store_true", help="RT_FLAG_NO_FILTER: every ray-primitive pair through the literal full test")
-    ap.add_argument("--plain-test", action="store_true", help="with --brute-force: RT_FLAG_PLAIN_TEST, the triangle test exactly as written (three IEEE divisions per pair)")
-    ap.add_argument("--cpu-crop", default="240x135", help="centred crop the CPU baseline renders (WxH)")
+    ap.add_argument("--brute-force", action="store_true", help="time the frames themselves with RT_FLAG_NO_FILTER (slow: for small sizes)")
+    ap.add_argument("--plain-test", action="store_true", help="brute-force scans use RT_FLAG_PLAIN_TEST: the triangle test exactly as written (three IEEE divisions per pair)")
+    ap.add_argument("--brute-crop", default="", help="centred crop of the brute-force leg (WxH)")
+    ap.add_argument("--cpu-crop", default="", help="centred crop the CPU baseline renders (WxH)")
     return ap.parse_args()
 
 
@@ -60,10 +74,10 @@ def load_workload(api, name, width, height, maxdepth):
     return fi, label, parse_s
 
 
-def flops_of(stats, n_point_lights_share=1.0):
-    closest = stats.closest_tests[0] * FLOP_TRI + stats.closest_tests[1] * FLOP_SPH + stats.closest_tests[2] * FLOP_ELL_CLOSEST
-    shadow = stats.shadow_tests[0] * FLOP_TRI + stats.shadow_tests[1] * FLOP_SPH + stats.shadow_tests[2] * FLOP_ELL_SHADOW_POINT
-    return closest, shadow
+def centred(fi, crop):
+    cw, ch = [int(v) for v in crop.split("x")]
+    cw, ch = min(cw, fi.width), min(ch, fi.height)
+    return dict(rect_x0=(fi.width - cw) // 2, rect_y0=(fi.height - ch) // 2, rect_w=cw, rect_h=ch), cw, ch
 
 
 def main():
@@ -101,6 +115,12 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     api.init(local_rank)
 
+    if args.workload == "synthetic" and world > 1:
+        # one rank writes the scene file, the others wait for it
+        if rank == 0:
+            from raytracer_amd import synth
+            synth.ensure_scene_file()
+        dist.barrier()
     fi, label, parse_s = load_workload(api, args.workload, args.width, args.height, args.maxdepth)
     depth = fi.max_recursion_depth if args.maxdepth < 0 else args.maxdepth
     cam = fi.camera()
@@ -120,6 +140,7 @@ def main():
     gathered = [torch.zeros(world * stride * TILE_BYTES, dtype=torch.uint8, device=device) if world > 1 else tiles[i] for i in range(2)]
     exchanged = [None, None]
     frame = torch.zeros(fi.height * fi.width * 3, dtype=torch.uint8, device=device) if rank == 0 else None
+    torch.cuda.synchronize()      # the library writes these buffers from streams of its own
 
     def barrier():
         if world > 1:
@@ -179,12 +200,8 @@ def main():
 
     if rank == 0:
         rays = tot["closest_rays"] + tot["shadow_rays"]
-        tests = tot["ct_tri"] + tot["ct_sph"] + tot["ct_ell"] + tot["st_tri"] + tot["st_sph"] + tot["st_ell"]
-        closest_flop = tot["ct_tri"] * FLOP_TRI + tot["ct_sph"] * FLOP_SPH + tot["ct_ell"] * FLOP_ELL_CLOSEST
-        shadow_flop = tot["st_tri"] * FLOP_TRI + tot["st_sph"] * FLOP_SPH + tot["st_ell"] * FLOP_ELL_SHADOW_POINT
-        # dominant kernel: k_closest. Per-GPU figure: this rank-summed FLOP over rank-summed kernel time.
-        closest_tflops = closest_flop / (tot["closest_ms"] * 1e-3) / 1e12 if tot["closest_ms"] > 0 else 0.0
-        shadow_tflops = shadow_flop / (tot["shadow_ms"] * 1e-3) / 1e12 if tot["shadow_ms"] > 0 else 0.0
+        pairs = tot["ct_tri"] + tot["ct_sph"] + tot["ct_ell"] + tot["st_tri"] + tot["st_sph"] + tot["st_ell"]
+        executed_tests = tot["pp_closest"] + tot["pp_shadow"] + tot["q_closest"] + tot["q_shadow"] + tot["full_tests"]
         out = {
             "metric": "Mrays/s",
             "value": rays / elapsed / 1e6,
@@ -202,44 +219,34 @@ def main():
                        "primitives": {"triangles": int(fi.scene_desc.n_triangles), "spheres": int(fi.scene_desc.n_spheres),
                                       "ellipsoids": int(fi.scene_desc.n_ellipsoids)},
                        "lights": int(fi.scene_desc.n_point_lights) + int(fi.scene_desc.has_directional_light),
-                       "parallelism": "tiles%%%d" % world},
-            "ray_prim_tests_per_s": tests / elapsed,
+                       "parallelism": "tiles%%%d" % world,
+                       "mode": "brute force (RT_FLAG_NO_FILTER)" if args.brute_force else "bounding hierarchy + conservative pre-tests, exact test on the survivors"},
             "rays_per_step": rays / args.steps,
-            "tests_per_step": tests / args.steps,
             "culled_samples_per_step": tot["culled"] / args.steps,
-            "pair_pretests_per_step": [tot["pp_closest"] / args.steps, tot["pp_shadow"] / args.steps],
-            "queued_pairs_per_step": [tot["q_closest"] / args.steps, tot["q_shadow"] / args.steps],
-            "full_tests_per_step": tot["full_tests"] / args.steps,
-            "roofline": {
-                "bound": "valu_fp32",
-                "kernel": "k_closest",
-                "achieved": closest_tflops,
-                "peak": PEAK_FP32_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": closest_tflops / PEAK_FP32_TFLOPS,
-                "traffic": measured_traffic(label, args.brute_force),
-                "executed": None if args.brute_force else {
-                    "tflops": tot["xf_closest"] / (tot["closest_ms"] * 1e-3) / 1e12 if tot["closest_ms"] > 0 else 0.0,
-                    "frac": (tot["xf_closest"] / (tot["closest_ms"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS) if tot["closest_ms"] > 0 else 0.0,
-                    "what": "FLOP of the per-ray tests the hierarchy scans executed (box tests 24, two-stage pre-test 40, full test 54 / 19 / 95) / the same kernel time"},
-                "mode": "brute force (literal full test on every pair)" if args.brute_force else "bounding hierarchy + conservative pre-tests, full test on the survivors",
-                "note": ROOFLINE_NOTE,
-                "flop_per_launch": closest_flop / max(tot["closest_launches"], 1.0),
-                "avg_launch_ms": tot["closest_ms"] / max(tot["closest_launches"], 1.0),
-                "launches": int(tot["closest_launches"]),
-                "shadow_kernel": {"kernel": "k_shadow", "achieved": shadow_tflops, "frac": shadow_tflops / PEAK_FP32_TFLOPS,
-                                  "avg_launch_ms": tot["shadow_ms"] / max(tot["shadow_launches"], 1.0), "launches": int(tot["shadow_launches"])},
-                "whole_step_tflops": (closest_flop + shadow_flop) / elapsed / 1e12 / world,
-            },
             "per_rank_max_ms": {k: v / args.steps for k, v in rank_max.items()},
             "setup_ms": {"parse_scene_file": parse_s * 1e3, "scene_create": scene_create_s * 1e3},   # rank 0, outside the timed steps
         }
+        if args.workload == "synthetic":
+            out["config"]["generator"] = SYNTHETIC_NOTES
         if not args.brute_force:
+            out["culled_mode"] = {
+                "what": "work of the timed frames: the hierarchy decides most ray-primitive pairs by bounds; executed = per-ray box tests + leaf pre-tests / tests + full triangle tests",
+                "executed_tests_per_s": executed_tests / elapsed,
+                "executed_tests_per_ray": executed_tests / max(rays, 1.0),
+                "executed_tflops": (tot["xf_closest"] + tot["xf_shadow"]) / elapsed / 1e12 / world,
+                "executed_frac_of_fp32_peak": (tot["xf_closest"] + tot["xf_shadow"]) / elapsed / 1e12 / world / PEAK_FP32_TFLOPS,
+                "pairs_decided_by_bounds": 1.0 - (tot["q_closest"] + tot["q_shadow"]) / max(pairs, 1.0),
+                "equivalent_ray_prim_pairs_per_s": pairs / elapsed,
+                "equivalent_note": "rays x primitives a brute-force renderer would visit for these frames, per second of this renderer; not executed work",
+                "full_triangle_tests_per_step": tot["full_tests"] / args.steps,
+            }
             # the frame the ranks assembled in the last step against one rendered by this rank alone (outside the timed steps)
             alone = scene.render(cam, fi.params(max_bounce_count=depth, flags=flags))
             out["frame_identical_to_single_rank_render"] = bool((alone["rgb"].reshape(-1) == frame.cpu().numpy()).all())
+        if not args.no_brute_force_leg:
+            out["roofline"] = brute_force_leg(abi, fi, cam, scene, depth, args, label)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(api, abi, fi, cam, scene, depth, args.cpu_crop)
+            out["cpu_baseline"] = cpu_baseline(api, abi, fi, cam, scene, depth, args.cpu_crop or CPU_CROP.get(args.workload, CPU_CROP["default"]))
         sys.stdout.flush()
         os.write(results_fd, (json.dumps(out) + "\n").encode())
 
@@ -249,18 +256,55 @@ def main():
         dist.destroy_process_group()
 
 
-ROOFLINE_NOTE = ("achieved = ray-primitive tests x FLOP of the reference formulation (54 triangle, 19 sphere, 95 ellipsoid) / HIP-event time of the "
-                 "closest-hit scan launches; in the default mode most tests are decided by bounds, so frac is above 1 and is not a utilisation: "
-                 "executed VALU utilisation (PMC) is in profiles/")
+def brute_force_leg(abi, fi, cam, scene, depth, args, label):
+    """Every ray against every primitive (RT_FLAG_NO_FILTER) on a centred crop of the same frame; one chunk, one stream,
+    launches one after the other, each between two HIP events on the stream it is launched on (rt_stats.*_kind_ms).
+    The dominant kernels are the brute-force triangle scans: closest hit (k_closest_tri_brute) and shadow (k_shadow_tri_brute)."""
+    crop = args.brute_crop or BRUTE_CROP.get(args.workload, BRUTE_CROP["default"])
+    rect, cw, ch = centred(fi, crop)
+    flags = abi.RT_FLAG_NO_FILTER | (abi.RT_FLAG_PLAIN_TEST if args.plain_test else 0)
+    prm = fi.params(max_bounce_count=depth, flags=flags, **rect)
+    brute = scene.render(cam, prm)
+    fast = scene.render(cam, fi.params(max_bounce_count=depth, **rect))
+    st = brute["stats"]
+    n_tri = int(fi.scene_desc.n_triangles)
+
+    def kernel(name, pairs, ms, launches):
+        tflops = pairs * FLOP_TRI / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return {"kernel": name, "achieved": tflops, "frac": tflops / PEAK_FP32_TFLOPS, "pairs": pairs, "pairs_per_s": pairs / (ms * 1e-3) if ms > 0 else 0.0,
+                "launches": int(launches), "avg_launch_ms": ms / max(launches, 1), "flop_per_launch": pairs * FLOP_TRI / max(launches, 1)}
+
+    variant = "false" if args.plain_test else "true"
+    closest = kernel("k_closest_tri_brute<1,%s>" % variant, float(st.closest_tests[0]), st.closest_kind_ms[0], st.closest_kind_launches[0])
+    shadow = kernel("k_shadow_tri_brute<1,%s>" % variant, float(st.shadow_tests[0]), st.shadow_kind_ms[0], st.shadow_kind_launches[0])
+    measured = profile_figures(label, args.plain_test)
+    out = {"bound": "valu_fp32", "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s"}
+    out.update(closest)
+    out.update({
+        "traffic": measured.get("closest_hbm_bytes_per_launch"),
+        "valu_issue_utilisation": measured.get("closest_valu_issue_utilisation"),
+        "what": "ray-triangle pairs x 54 FLOP of the reference's test / HIP-event time of the launches; every pair is visited, the test is evaluated in "
+                "stages that skip what the outcome does not depend on (results identical to the test as written, which --plain-test runs)",
+        "sample": "centred %dx%d-pixel crop of %s, maxdepth %d: %d closest-hit rays, %d shadow rays, %d triangles" % (cw, ch, label, depth, st.closest_rays, st.shadow_rays, n_tri),
+        "shadow_kernel": dict(shadow, traffic=measured.get("shadow_hbm_bytes_per_launch"), valu_issue_utilisation=measured.get("shadow_valu_issue_utilisation"),
+                              pairs_counted="primitives scanned while the ray was still unblocked"),
+        "dominant_by_time": "k_shadow_tri_brute" if st.shadow_kind_ms[0] > st.closest_kind_ms[0] else "k_closest_tri_brute",
+        "other_kinds_ms": {"closest_sphere": st.closest_kind_ms[1], "closest_ellipsoid": st.closest_kind_ms[2], "shadow_sphere": st.shadow_kind_ms[1], "shadow_ellipsoid": st.shadow_kind_ms[2]},
+        "leg_device_ms": st.device_ms,
+        "image_identical_to_default_mode": bool((brute["rgb"] == fast["rgb"]).all()),
+        "counters_identical_to_default_mode": all(getattr(st, f) == getattr(fast["stats"], f) for f in ("closest_rays", "hits", "shadow_rays", "shadow_blocked")),
+    })
+    return out
 
 
-def measured_traffic(label, brute_force):
-    """HBM bytes per closest-hit scan launch of this workload from the committed rocprofv3 PMC pass (profiles/traffic.json), or None."""
+def profile_figures(label, plain):
+    """Figures of the brute-force kernels from the committed rocprofv3 PMC passes (profiles/traffic.json), or {}."""
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        return table.get(label + ("/brute-force" if brute_force else ""))
+        got = table.get(label + ("/brute-force-plain" if plain else "/brute-force"))
+        return got if isinstance(got, dict) else {}
     except (OSError, ValueError):
-        return None
+        return {}
 
 
 def cpu_baseline(api, abi, fi, cam, scene, depth, crop):
@@ -272,9 +316,8 @@ def cpu_baseline(api, abi, fi, cam, scene, depth, crop):
     """
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import checkers
-    cw, ch = [int(v) for v in crop.split("x")]
-    cw, ch = min(cw, fi.width), min(ch, fi.height)
-    prm = fi.params(max_bounce_count=depth, rect_x0=(fi.width - cw) // 2, rect_y0=(fi.height - ch) // 2, rect_w=cw, rect_h=ch)
+    rect, cw, ch = centred(fi, crop)
+    prm = fi.params(max_bounce_count=depth, **rect)
     g = scene.render(cam, prm)
     rays = g["stats"].closest_rays + g["stats"].shadow_rays
     threads = min(os.cpu_count() or 1, 16)
@@ -284,9 +327,19 @@ def cpu_baseline(api, abi, fi, cam, scene, depth, crop):
         lib, prefix, kind = checkers.load_oracle(), "rto_", "port"
     r = checkers.cpu_render(lib, prefix, fi.scene_desc, cam, prm, threads=threads)
     same = bool((r["rgb"] == g["rgb"]).all())
-    return {"value": rays / r["seconds"] / 1e6, "unit": "Mrays/s", "cores": threads, "kind": kind,
+    return {"value": rays / r["seconds"] / 1e6, "unit": "Mrays/s", "cores": threads, "kind": kind, "cpu_model": cpu_model(),
             "sample": "centred %dx%d-pixel crop of the same frame (%d rays), %.1f s" % (cw, ch, rays, r["seconds"]),
             "seconds": r["seconds"], "image_identical_to_gpu": same}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 if __name__ == "__main__":

@@ -120,7 +120,10 @@ typedef struct rt_stats {
     uint64_t hits;                /* of which hit something */
     uint64_t shadow_rays;         /* shadow ray segments */
     uint64_t shadow_blocked;      /* of which blocked */
-    uint64_t closest_tests[3];    /* ray-primitive tests, closest hit: triangle, sphere, ellipsoid (unpadded counts) */
+    uint64_t closest_tests[3];    /* ray-primitive PAIRS of the closest-hit search: rays x unpadded count of triangles, spheres, ellipsoids.
+                                     With RT_FLAG_NO_FILTER every pair is visited by a brute-force scan; in the default mode the
+                                     bounding hierarchy decides most pairs without visiting them (pair_pretests, queued_pairs and
+                                     full_tests count what was executed) */
     uint64_t shadow_tests[3];     /* ray-primitive tests, shadow rays, up to the point the ray's wave stopped scanning */
     double   device_ms;           /* HIP-event time of all launches of this call */
     double   closest_ms;          /* HIP-event time summed over the closest-hit scan launches */
@@ -131,6 +134,11 @@ typedef struct rt_stats {
     uint64_t pair_pretests[2];    /* per-ray box tests of the hierarchy scans (top nodes the per-wave test kept, and children of kept nodes): closest-hit scans, shadow scans */
     uint64_t queued_pairs[2];     /* (ray, primitive) pairs the boxes left over, i.e. sent to the two-stage pre-test (triangles) or the full test: closest-hit scans, shadow scans */
     uint64_t executed_flop[2];    /* FLOP the hierarchy scans executed in per-ray tests (box test 24, two-stage pre-test 40, full test 54 triangle / 19 sphere / 95 or 71 ellipsoid): closest-hit scans, shadow scans */
+    double   closest_kind_ms[3];  /* HIP-event time of the closest-hit scan launches per kind: triangle, sphere, ellipsoid (their sum is closest_ms
+                                     only when launches do not overlap: RT_FLAG_NO_FILTER runs them one after the other) */
+    double   shadow_kind_ms[3];   /* the same for the shadow scans */
+    uint64_t closest_kind_launches[3];
+    uint64_t shadow_kind_launches[3];
 } rt_stats;
 
 typedef struct rt_scene rt_scene;          /* opaque: device-resident scene */

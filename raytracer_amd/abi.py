@@ -78,6 +78,10 @@ class Stats(C.Structure):
         ("pair_pretests", C.c_uint64 * 2),
         ("queued_pairs", C.c_uint64 * 2),
         ("executed_flop", C.c_uint64 * 2),
+        ("closest_kind_ms", C.c_double * 3),
+        ("shadow_kind_ms", C.c_double * 3),
+        ("closest_kind_launches", C.c_uint64 * 3),
+        ("shadow_kind_launches", C.c_uint64 * 3),
     ]
 
     def as_dict(self):

@@ -106,6 +106,7 @@ def ensure_scene_file(directory=None, **kwargs):
     """Path of the scene for these parameters, generated on first use (about a minute for the full size)."""
     directory = directory or os.environ.get("RT_SYNTH_DIR") or tempfile.gettempdir()
     tag = "_".join("%s%s" % (k[:3], str(kwargs[k]).replace(" ", "").replace("(", "").replace(")", "").replace(",", "-")) for k in sorted(kwargs)) or "default"
+    os.makedirs(directory, exist_ok=True)
     path = os.path.join(directory, "rt_synthetic_%s.test" % tag)
     if not os.path.exists(path):
         write_scene(path, **kwargs)
