@@ -47,7 +47,7 @@ def main():
     if merged:
         out.append("\n== rocprofv3 --pmc, summed over the dispatches of each kernel (three separate passes)")
         for kernel, cs in merged.items():
-            if not any(k in kernel for k in ("k_closest", "k_shadow", "k_primary", "k_shade", "k_resolve")):
+            if not any(k in kernel for k in ("k_closest", "k_shadow", "k_primary", "k_shade", "k_resolve", "k_hit")):
                 continue
             out.append("\n%s" % kernel)
             for counter, (n, total, dur) in sorted(cs.items()):
@@ -84,21 +84,34 @@ def main():
             for line in open(path):
                 if line.startswith('{"metric"'):
                     out.append("\n== bench.py line of the %s run\n%s" % (log.replace(".log", ""), line.strip()))
-    # HBM bytes per closest-hit scan launch (what bench.py reports as roofline.traffic), keyed by the workload of the PMC runs
-    closest = [cs for kernel, cs in merged.items() if "k_closest_scan" in kernel and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs]
-    label = None
-    for line in open(os.path.join(src, "pmc_sq.log")) if os.path.exists(os.path.join(src, "pmc_sq.log")) else []:
-        if line.startswith('{"metric"'):
-            label = json.loads(line)["config"]["workload"]
-    if closest and label and len(sys.argv) > 3:
-        launches = sum(cs["FETCH_SIZE"][0] for cs in closest)
-        total = sum(2.0 * 1024.0 * cs["FETCH_SIZE"][1] + 1024.0 * cs["WRITE_SIZE"][1] for cs in closest)
-        table = {}
-        if os.path.exists(sys.argv[3]):
-            table = json.load(open(sys.argv[3]))
-        table[label] = total / launches
+    # Figures of the brute-force triangle scans that bench.py reports in its roofline object (traffic, VALU issue
+    # utilisation), keyed by the workload of the PMC runs; and VALU instructions per (wave, triangle) step.
+    line = None
+    for log in ("pmc_sq.log", "trace.log"):
+        path = os.path.join(src, log)
+        for text in open(path) if os.path.exists(path) else []:
+            if text.startswith('{"metric"'):
+                line = json.loads(text)
+    if line and "roofline" in line and len(sys.argv) > 3:
+        label = line["config"]["workload"] + ("/brute-force-plain" if "false" in line["roofline"]["kernel"] else "/brute-force")
+        entry = {}
+        for tag, name, pairs in (("closest", "k_closest_tri_brute", line["roofline"]["pairs"]), ("shadow", "k_shadow_tri_brute", line["roofline"]["shadow_kernel"]["pairs"])):
+            cs = [v for k, v in merged.items() if name in k]
+            if not cs:
+                continue
+            cs = cs[0]
+            g = lambda c: cs[c][1] if c in cs else None
+            if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+                entry[tag + "_hbm_bytes_per_launch"] = (2.0 * 1024.0 * g("FETCH_SIZE") + 1024.0 * g("WRITE_SIZE")) / cs["FETCH_SIZE"][0]
+            if g("SQ_INSTS_VALU") and g("GRBM_GUI_ACTIVE"):
+                cycles = g("GRBM_GUI_ACTIVE") / 8.0 * (float(cs["SQ_INSTS_VALU"][0]) / cs["GRBM_GUI_ACTIVE"][0])
+                entry[tag + "_valu_issue_utilisation"] = 2.0 * g("SQ_INSTS_VALU") / (cycles * 1024.0)
+            if g("SQ_INSTS_VALU") and pairs:
+                entry[tag + "_valu_instructions_per_wave_and_triangle"] = g("SQ_INSTS_VALU") / (pairs / 64.0)
+        table = json.load(open(sys.argv[3])) if os.path.exists(sys.argv[3]) else {}
+        table[label] = entry
         json.dump(table, open(sys.argv[3], "w"), indent=1, sort_keys=True)
-        out.append("\n== HBM bytes per closest-hit scan launch (%s): %.4e  -> %s" % (label, total / launches, sys.argv[3]))
+        out.append("\n== brute-force triangle scans (%s) -> %s\n%s" % (label, sys.argv[3], json.dumps(entry, indent=1)))
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     with open(dst, "w") as f:
         f.write("\n".join(out) + "\n")
