@@ -141,6 +141,9 @@ typedef struct rt_stats {
     uint64_t shadow_kind_launches[3];
 } rt_stats;
 
+/* Thread safety: the library renders on one GPU per process with one set of streams and ray-state arenas; rt_scene_create,
+ * the render calls and rt_assemble_tiles_device take a library lock, so concurrent calls are safe and run one after the other
+ * (the reference's render_scanline is re-entrant; parallelism here is inside a call). */
 typedef struct rt_scene rt_scene;          /* opaque: device-resident scene */
 typedef struct rt_file_info rt_file_info;  /* opaque: a parsed .test file */
 
@@ -173,6 +176,14 @@ int rt_render(const rt_scene* scene, const rt_camera_desc* camera, const rt_rend
  * RCCL gather consumes device buffers, and by the benchmark. */
 int rt_render_tiles_device(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params,
                            void* tiles_dev, rt_stats* stats);
+/* rt_render_tiles_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid it); it has no counterpart in the reference.  The call allocates, creates and frees nothing:
+ * the per-sample state lives in a fixed device array of the library (about 37 MB per GPU, held until the process ends),
+ * so this rank's share of the rectangle may be at most RT_NOALLOC_MAX_TILES tiles (e.g. 128x128 pixels); a larger one is
+ * refused with an error.  Same tile buffer, same bytes as rt_render_tiles_device; no statistics.  Every call on a GPU
+ * uses the same array: calls are serialised inside the library, and the array's contents do not outlive a call. */
+#define RT_NOALLOC_MAX_TILES 64
+int rt_render_tiles_noalloc(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params, void* tiles_dev);
 /* Number of tiles rank `tile_rank` of `tile_world` renders for these params. */
 uint32_t rt_rank_tile_count(const rt_render_params* params);
 /* Total tiles of the rectangle. */

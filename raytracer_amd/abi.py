@@ -94,6 +94,7 @@ class Stats(C.Structure):
 
 RT_TILE = 16
 RT_SAMPLES_PER_PIXEL = 16
+RT_NOALLOC_MAX_TILES = 64
 RT_FLAG_NO_FILTER = 1
 RT_FLAG_WALK_ALL = 2
 RT_FLAG_DEEP_WALK = 4
@@ -112,6 +113,7 @@ PROTOTYPES = {
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_render": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "rt_render_tiles_device": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]),
+    "rt_render_tiles_noalloc": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p]),
     "rt_rank_tile_count": (C.c_uint32, [C.POINTER(RenderParams)]),
     "rt_total_tile_count": (C.c_uint32, [C.POINTER(RenderParams)]),
     "rt_assemble_tiles_device": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(RenderParams), C.c_void_p]),

@@ -141,6 +141,11 @@ class Scene:
         return stats
 
 
+def render_tiles_noalloc(scene, camera, params, tiles_dev_ptr):
+    """rt_render_tiles_noalloc into caller-owned device memory (an integer address)."""
+    _check(lib().rt_render_tiles_noalloc(scene._h, C.byref(camera), C.byref(params), C.c_void_p(tiles_dev_ptr)))
+
+
 def rank_tile_count(params):
     return lib().rt_rank_tile_count(C.byref(params))
 

@@ -166,6 +166,8 @@ struct V3 { float x, y, z; };
 // arithmetic building blocks
 // ------------------------------------------------------------------------------------------
 #define DEV __device__ __forceinline__
+#define RT_STRINGIFY_(x) #x
+#define RT_STRINGIFY(x) RT_STRINGIFY_(x)
 
 DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 DEV float fp_min(float x, float y) { return x < y ? x : y; }   // minss: second operand on NaN (maths.cpp:147-152)
@@ -2414,6 +2416,8 @@ struct Library {
     hipStream_t stream = nullptr;           // = lanes[0].stream: uploads, scene preparation, assembly
     hipEvent_t lanes_fork = nullptr, lanes_join[MAX_LANES] = {}, lanes_started[MAX_LANES] = {};
     unsigned long long* stats = nullptr;    // STAT_COPIES x ST_COUNT words
+    unsigned char* scratch = nullptr;       // device address of `scratch` on this device (hipGetSymbolAddress)
+    std::mutex guard;                       // one call at a time uses the lanes, the arenas and the counters
     std::vector<hipEvent_t> events;
 };
 Library g_lib;
@@ -2491,19 +2495,32 @@ struct rt_scene {
 
 namespace {
 
+// bytes of per-sample state for a chunk of `samples` samples (a multiple of 4096):
+// 24 float arrays + hit_id + blocked + 2 lists + primary ids + three 64-bit keys = 35 words per sample
+// + per 256 samples: 4 wave ballots and one offset (ordered compaction) + the block totals of the two-level scan
+constexpr size_t state_bytes(size_t samples) { return samples * 35 * sizeof(float) + samples / BLOCK * 40 + SCAN_THREADS * sizeof(uint32_t); }
+
+// Scratch of rt_render_tiles_noalloc: the per-sample state of one chunk of at most NOALLOC_MAX_TILES tiles, then 64 list
+// lengths, then the work counters.  Device code and host code reach it only through the address
+// rt_init obtains with hipGetSymbolAddress (g_lib.scratch): the name below is not a device address on the host side.
+constexpr uint32_t NOALLOC_MAX_TILES = RT_NOALLOC_MAX_TILES;
+constexpr size_t NOALLOC_STATE_BYTES = (state_bytes(static_cast<size_t>(NOALLOC_MAX_TILES) * SAMPLES_PER_TILE) + 255) / 256 * 256;
+constexpr size_t NOALLOC_COUNTS_BYTES = 256;                                      // 64 words
+constexpr size_t NOALLOC_STATS_BYTES = STAT_COPIES * ST_COUNT * sizeof(unsigned long long);
+constexpr size_t NOALLOC_BYTES = NOALLOC_STATE_BYTES + NOALLOC_COUNTS_BYTES + NOALLOC_STATS_BYTES;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+
 int ensure_state(Lane& lane, size_t samples) {
     if (lane.state_samples >= samples) return 0;
     if (lane.state_mem) { HIP_TRY(hipFree(lane.state_mem)); lane.state_mem = nullptr; lane.state_samples = 0; }
-    // 24 float arrays + hit_id + blocked + 2 lists + primary ids + three 64-bit keys = 35 words per sample
-    // + per 256 samples: 4 wave ballots and one offset (ordered compaction)
-    HIP_TRY(hipMalloc(&lane.state_mem, samples * 35 * sizeof(float) + samples / BLOCK * 40 + SCAN_THREADS * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&lane.state_mem, state_bytes(samples)));
     lane.state_samples = samples;
     return 0;
 }
 
-State make_state(const Lane& lane, size_t samples, bool want_ids) {
+State make_state(void* state_mem, uint32_t* counts, unsigned long long* stats, size_t samples, bool want_ids) {
     State st;
-    float* f = static_cast<float*>(lane.state_mem);
+    float* f = static_cast<float*>(state_mem);
     float** fields[] = {&st.ox, &st.oy, &st.oz, &st.dx, &st.dy, &st.dz, &st.wr, &st.wg, &st.wb, &st.cr, &st.cg, &st.cb,
                         &st.px, &st.py, &st.pz, &st.nx, &st.ny, &st.nz, &st.nox, &st.noy, &st.noz, &st.ndx, &st.ndy, &st.ndz};
     size_t k = 0;
@@ -2517,8 +2534,8 @@ State make_state(const Lane& lane, size_t samples, bool want_ids) {
     st.flag_bits = st.key_sph + samples;                               // 16-byte aligned likewise
     st.wg_offset = reinterpret_cast<uint32_t*>(st.flag_bits + samples / BLOCK * 4);
     st.scan_block = st.wg_offset + samples / BLOCK + samples / BLOCK % 2;   // after the offsets (8 bytes of the 40 per workgroup are spare)
-    st.counts = lane.counts;
-    st.stats = g_lib.stats;
+    st.counts = counts;
+    st.stats = stats;
     return st;
 }
 
@@ -2599,8 +2616,9 @@ void launch_shadow_scan(bool deep, dim3 grid, hipStream_t on, const DevScene& sc
 }
 
 int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_render_params* prm, uint8_t* tiles_dev,
-                uint32_t* ids_dev /* rect-shaped, nullable */, rt_stats* stats) {
+                uint32_t* ids_dev /* rect-shaped, nullable */, rt_stats* stats, bool no_alloc = false) {
     if (!g_lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    std::lock_guard<std::mutex> one_at_a_time(g_lib.guard);
     if (!scene || !cam || !prm) return rt_fail(RT_ERR_ARGUMENT, "null argument");
     if (prm->width == 0 || prm->height == 0) return rt_fail(RT_ERR_ARGUMENT, "image size is zero");
     if (prm->max_bounce_count < 0 || static_cast<uint32_t>(prm->max_bounce_count) > MAX_BOUNCES) return rt_fail(RT_ERR_LIMIT, "max_bounce_count out of range (0..62)");
@@ -2615,9 +2633,15 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     // unless the caller fixed the chunk size, a frame that would be one chunk is cut into one chunk per lane
     // (not in brute-force mode, whose launches are timed one by one)
     if (prm->chunk_tiles == 0 && (prm->flags & RT_FLAG_NO_FILTER) == 0 && my_tiles <= chunk_tiles && my_tiles >= 2 * MIN_LANE_TILES) chunk_tiles = ceil_div(my_tiles, std::min(MAX_LANES, my_tiles / MIN_LANE_TILES));
+    if (no_alloc) {   // one chunk on one lane, its state in the scratch array: nothing is allocated, created or freed below
+        if (my_tiles > NOALLOC_MAX_TILES) return rt_fail(RT_ERR_LIMIT, "rt_render_tiles_noalloc: more than " RT_STRINGIFY(RT_NOALLOC_MAX_TILES) " tiles of 16x16 pixels for this rank");
+        chunk_tiles = my_tiles ? my_tiles : 1;
+    }
     const size_t chunk_samples = static_cast<size_t>(chunk_tiles) * SAMPLES_PER_TILE;
     const uint32_t n_lanes = std::min(MAX_LANES, ceil_div(my_tiles, chunk_tiles));
-    for (uint32_t l = 0; l < n_lanes; ++l) if (int rc = ensure_state(g_lib.lanes[l], chunk_samples)) return rc;
+    if (!no_alloc) for (uint32_t l = 0; l < n_lanes; ++l) if (int rc = ensure_state(g_lib.lanes[l], chunk_samples)) return rc;
+    unsigned long long* const stats_dev = no_alloc ? reinterpret_cast<unsigned long long*>(g_lib.scratch + NOALLOC_STATE_BYTES + NOALLOC_COUNTS_BYTES) : g_lib.stats;
+    auto counts_of = [&](uint32_t l) { return no_alloc ? reinterpret_cast<uint32_t*>(g_lib.scratch + NOALLOC_STATE_BYTES) : g_lib.lanes[l].counts; };
 
     DevScene sc = scene->dev;
     hipStream_t stream = g_lib.stream;
@@ -2643,8 +2667,9 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     f.tiles_x = rect.tiles_x; f.tile_rank = prm->tile_rank; f.tile_world = world;
 
     State lane_state[MAX_LANES];
-    for (uint32_t l = 0; l < n_lanes; ++l) lane_state[l] = make_state(g_lib.lanes[l], chunk_samples, ids_dev != nullptr);
-    HIP_TRY(hipMemsetAsync(g_lib.stats, 0, STAT_COPIES * ST_COUNT * sizeof(unsigned long long), stream));
+    for (uint32_t l = 0; l < n_lanes; ++l)
+        lane_state[l] = make_state(no_alloc ? static_cast<void*>(g_lib.scratch) : g_lib.lanes[l].state_mem, counts_of(l), stats_dev, chunk_samples, ids_dev != nullptr);
+    HIP_TRY(hipMemsetAsync(stats_dev, 0, STAT_COPIES * ST_COUNT * sizeof(unsigned long long), stream));
 
     Timer timer_storage;
     Timer* timer = stats ? &timer_storage : nullptr;
@@ -2677,7 +2702,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         const State st = lane_state[chunk % n_lanes];
         const uint32_t n_tiles = (my_tiles - first < chunk_tiles) ? my_tiles - first : chunk_tiles;
         const uint32_t n_samples = n_tiles * SAMPLES_PER_TILE;
-        HIP_TRY(hipMemsetAsync(lane.counts, 0, 64 * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(st.counts, 0, 64 * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(k_primary, dim3(n_samples / BLOCK), dim3(BLOCK), 0, stream, f, sc, st, first);
         const uint32_t scan_grid = ceil_div(n_samples / BLOCK, SCAN_THREADS);
         hipLaunchKernelGGL(k_scan_flags, dim3(scan_grid), dim3(SCAN_THREADS), 0, stream, st, static_cast<const uint32_t*>(nullptr), n_samples);
@@ -2782,7 +2807,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
             hipLaunchKernelGGL(k_fill_list, dim3(ray_blocks()), dim3(BLOCK), 0, stream, sb, static_cast<const uint32_t*>(sb.counts + b), 0u,
                                static_cast<const uint32_t*>(sb.list[b & 1u]), sb.list[(b + 1) & 1u]);
             if (int rc = fetch_count(b + 1)) return rc;
-            const bool overlap = filter && b + 1 < depth;   // brute force is timed launch by launch: no overlap there
+            const bool overlap = filter && b + 1 < depth && !no_alloc;   // brute force is timed launch by launch: no overlap there; the fork / join events are created on demand
             hipEvent_t forked = overlap ? sync_event(lane, 2 * b) : nullptr, joined = overlap ? sync_event(lane, 2 * b + 1) : nullptr;
             if (overlap && forked && joined) {
                 HIP_TRY(hipEventRecord(forked, stream));
@@ -2859,8 +2884,13 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         lane_rc[0] = run_lane(0);
         for (std::thread& t : helpers) t.join();
     }
-    if (lane_rc[0]) return lane_rc[0];
-    for (uint32_t l = 1; l < n_lanes; ++l) if (lane_rc[l]) return rt_fail(lane_rc[l], lane_error[l].c_str());
+    // A lane that failed leaves launches of the other lanes in flight, writing the caller's buffers: drain the device before returning.
+    for (uint32_t l = 0; l < n_lanes; ++l) {
+        if (!lane_rc[l]) continue;
+        if (l == 0) lane_error[0] = g_last_error;
+        (void)hipDeviceSynchronize();
+        return rt_fail(lane_rc[l], lane_error[l].c_str());
+    }
     for (uint32_t l = 1; l < n_lanes; ++l) {
         HIP_TRY(hipEventRecord(g_lib.lanes_join[l], g_lib.lanes[l].stream));
         HIP_TRY(hipStreamWaitEvent(stream, g_lib.lanes_join[l], 0));
@@ -2870,7 +2900,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
 
     if (stats) {
         unsigned long long copies[STAT_COPIES * ST_COUNT], h[ST_COUNT] = {};
-        HIP_TRY(hipMemcpy(copies, g_lib.stats, sizeof copies, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(copies, stats_dev, sizeof copies, hipMemcpyDeviceToHost));
         for (int c = 0; c < STAT_COPIES; ++c) for (int k = 0; k < ST_COUNT; ++k) h[k] += copies[c * ST_COUNT + k];
         std::memset(stats, 0, sizeof *stats);
         // samples inside the rectangle, from the tile geometry; the bounding box culled those that are not live
@@ -3120,6 +3150,20 @@ int upload(rt_scene* s, const T* host, size_t count, T** dev) {
     return 0;
 }
 
+// No C++ exception crosses the C boundary (std::thread and std::vector can throw): it becomes an error code.
+template <typename Body>
+int guarded(Body&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return rt_fail(RT_ERR_LIMIT, "out of host memory");
+    } catch (const std::exception& e) {
+        return rt_fail(RT_ERR_DEVICE, e.what());
+    } catch (...) {
+        return rt_fail(RT_ERR_DEVICE, "unknown C++ exception");
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -3154,6 +3198,9 @@ int rt_init(int device) {
     for (hipEvent_t& e : g_lib.lanes_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t& e : g_lib.lanes_started) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_lib.stats), STAT_COPIES * ST_COUNT * sizeof(unsigned long long)));
+    // this device's copy of the scratch array of rt_render_tiles_noalloc: its address, once, with the device current
+    HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&g_lib.scratch), HIP_SYMBOL(scratch)));
+    if (!g_lib.scratch) return rt_fail(RT_ERR_DEVICE, "rt_init: the scratch array has no device address");
     g_lib.device = device;
     g_lib.ready = true;
     return 0;
@@ -3165,10 +3212,18 @@ void rt_scene_destroy(rt_scene* scene) {
     delete scene;
 }
 
+static int scene_create_impl(const rt_scene_desc* desc, rt_scene** out);
 int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
     if (!g_lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
     if (!desc || !out) return rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: null argument");
     *out = nullptr;
+    std::lock_guard<std::mutex> one_at_a_time(g_lib.guard);
+    return guarded([&] { return scene_create_impl(desc, out); });
+}
+static int scene_create_impl(const rt_scene_desc* desc, rt_scene** out) {
+    if (desc->n_point_lights && !desc->point_light_sources) return rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: point_light_sources is null");
+    if ((desc->n_triangles && !desc->triangle_materials) || (desc->n_spheres && !desc->sphere_materials) || (desc->n_ellipsoids && !desc->ellipsoid_materials))
+        return rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: a material array is null");
     if (desc->n_triangle8 > (1u << 26) || desc->n_sphere8 > (1u << 26) || desc->n_ellipsoid8 > (1u << 26)) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^29 primitives of one kind");
     if (desc->n_triangles > desc->n_triangle8 * 8 || desc->n_spheres > desc->n_sphere8 * 8 || desc->n_ellipsoids > desc->n_ellipsoid8 * 8) return rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: more materials than primitive slots");
     if (desc->n_point_lights > 4096) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 4096 point lights");
@@ -3293,11 +3348,17 @@ uint32_t rt_total_tile_count(const rt_render_params* params) { return params ? r
 
 int rt_render_tiles_device(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params, void* tiles_dev, rt_stats* stats) {
     if (!tiles_dev) return rt_fail(RT_ERR_ARGUMENT, "rt_render_tiles_device: null output");
-    return render_impl(scene, camera, params, static_cast<uint8_t*>(tiles_dev), nullptr, stats);
+    return guarded([&] { return render_impl(scene, camera, params, static_cast<uint8_t*>(tiles_dev), nullptr, stats); });
+}
+
+int rt_render_tiles_noalloc(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params, void* tiles_dev) {
+    if (!tiles_dev) return rt_fail(RT_ERR_ARGUMENT, "rt_render_tiles_noalloc: null output");
+    return guarded([&] { return render_impl(scene, camera, params, static_cast<uint8_t*>(tiles_dev), nullptr, nullptr, true); });
 }
 
 int rt_assemble_tiles_device(const void* gathered, uint32_t stride_tiles, const rt_render_params* params, void* rgb_dev) {
     if (!g_lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    std::lock_guard<std::mutex> one_at_a_time(g_lib.guard);
     if (!gathered || !params || !rgb_dev) return rt_fail(RT_ERR_ARGUMENT, "rt_assemble_tiles_device: null argument");
     const Rect rect = rect_of(*params);
     const uint32_t world = params->tile_world ? params->tile_world : 1;
@@ -3326,7 +3387,7 @@ int rt_render(const rt_scene* scene, const rt_camera_desc* camera, const rt_rend
         return rt_fail(RT_ERR_DEVICE, "rt_render: out of device memory");
     }
     if (primary_id_out && hipMemsetAsync(ids_dev, 0xFF, n_px * 16 * sizeof(uint32_t), g_lib.stream) != hipSuccess) { cleanup(); return rt_fail(RT_ERR_DEVICE, "rt_render: memset failed"); }
-    rc = render_impl(scene, camera, params, tiles_dev, ids_dev, stats);
+    rc = guarded([&] { return render_impl(scene, camera, params, tiles_dev, ids_dev, stats); });
     if (rc == 0) {
         if (world == 1) {
             rc = rt_assemble_tiles_device(tiles_dev, my_tiles, params, rgb_dev);
