@@ -85,9 +85,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (args.gpus, world))
+    single_process = world == 1 and args.gpus > 1      # not under a launcher: one process drives all the GPUs (rt_init_devices / rt_render_multi)
+    if world != args.gpus and not single_process:
         args.gpus = world
 
     # The line of results is the only thing this program writes to its standard output: libraries that
@@ -107,13 +106,40 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if single_process:
+        return single_process_bench(args, api, abi, results_fd)
+    exchange = "none"
     if world > 1:
+        # torch.distributed is the launcher's rendezvous and the control plane only (barriers, the maximum of the ranks' times,
+        # handing out the communicator's identifier): gloo, on the host.  The tile buffers travel through the library's own RCCL communicator.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     api.init(local_rank)
+    if world > 1 and not rehearsal:
+        ok, uid = 1, None
+        if rank == 0:
+            try:
+                uid = api.comm_unique_id()
+            except Exception as e:   # reported, never silent: the line of results names the exchange that ran
+                sys.stderr.write("rank 0: RCCL identifier failed (%s)\n" % e)
+        ids = [uid]
+        dist.broadcast_object_list(ids, src=0)
+        try:
+            if ids[0] is None:
+                raise RuntimeError("rank 0 could not create the identifier")
+            api.comm_init_rank(ids[0], rank, world)
+            exchange = "library RCCL communicator: grouped send/receive to rank 0 (rt_comm_gather_tiles)"
+        except Exception as e:
+            sys.stderr.write("rank %d: library communicator failed (%s)\n" % (rank, e))
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            api.comm_destroy()
+            nccl_group = dist.new_group(backend="nccl")
+            exchange = "torch.distributed all_gather_into_tensor over RCCL (the library communicator could not be created)"
+    elif world > 1:
+        exchange = "gloo on host copies (rehearsal on one GPU)"
 
     if args.workload == "synthetic" and world > 1:
         # one rank writes the scene file, the others wait for it
@@ -121,6 +147,7 @@ def main():
             from raytracer_amd import synth
             synth.ensure_scene_file()
         dist.barrier()
+    use_library_comm = exchange.startswith("library")
     fi, label, parse_s = load_workload(api, args.workload, args.width, args.height, args.maxdepth)
     depth = fi.max_recursion_depth if args.maxdepth < 0 else args.maxdepth
     cam = fi.camera()
@@ -149,7 +176,9 @@ def main():
 
     def finish(k):
         """Frame k: wait for its exchange, then rank 0 scatters the gathered tiles into the image."""
-        if exchanged[k % 2] is not None:
+        if use_library_comm:
+            api.comm_wait()
+        elif exchanged[k % 2] is not None:
             exchanged[k % 2].synchronize()
         if rank == 0:
             api.assemble_tiles_device(gathered[k % 2].data_ptr(), stride, prm, frame.data_ptr())
@@ -160,8 +189,14 @@ def main():
             stats.append(scene.render_tiles_device(cam, prm, tiles[k % 2].data_ptr(), want_stats=True))   # returns with its streams idle
             if k:
                 finish(k - 1)
-            if world > 1:
-                dist.all_gather_into_tensor(gathered[k % 2], tiles[k % 2])
+            if use_library_comm:
+                api.comm_gather_tiles(tiles[k % 2].data_ptr(), stride, gathered[k % 2].data_ptr())     # enqueued on the library's exchange stream
+            elif world > 1 and rehearsal:
+                host = [torch.zeros(stride * TILE_BYTES, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(host, tiles[k % 2].cpu())
+                gathered[k % 2].copy_(torch.cat(host))
+            elif world > 1:
+                dist.all_gather_into_tensor(gathered[k % 2], tiles[k % 2], group=nccl_group)
                 exchanged[k % 2] = torch.cuda.Event()
                 exchanged[k % 2].record()
         if n:
@@ -175,7 +210,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -189,7 +224,7 @@ def main():
     local += [float(sum(s.executed_flop[k] for s in stats)) for k in range(2)]
     local += [sum(s.closest_ms for s in stats), sum(s.shadow_ms for s in stats), sum(s.device_ms for s in stats)]
     local += [float(sum(s.closest_launches for s in stats)), float(sum(s.shadow_launches for s in stats))]
-    acc = torch.tensor(local, dtype=torch.float64, device=device)
+    acc = torch.tensor(local, dtype=torch.float64)
     mx = acc.clone()
     if world > 1:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
@@ -219,7 +254,7 @@ def main():
                        "primitives": {"triangles": int(fi.scene_desc.n_triangles), "spheres": int(fi.scene_desc.n_spheres),
                                       "ellipsoids": int(fi.scene_desc.n_ellipsoids)},
                        "lights": int(fi.scene_desc.n_point_lights) + int(fi.scene_desc.has_directional_light),
-                       "parallelism": "tiles%%%d" % world,
+                       "parallelism": "tiles%%%d" % world, "exchange": exchange,
                        "mode": "brute force (RT_FLAG_NO_FILTER)" if args.brute_force else "bounding hierarchy + conservative pre-tests, exact test on the survivors"},
             "rays_per_step": rays / args.steps,
             "culled_samples_per_step": tot["culled"] / args.steps,
@@ -253,7 +288,40 @@ def main():
     scene.close()
     if world > 1:
         dist.barrier()
+        api.comm_destroy()
         dist.destroy_process_group()
+
+
+def single_process_bench(args, api, abi, results_fd):
+    """--gpus N without a launcher: this one process drives N GPUs through the C ABI alone (rt_init_devices, rt_scene_create
+    replicating the scene, rt_render_multi: one host thread per device, RCCL gather to device 0, image copied to the host)."""
+    n = args.gpus
+    api.init_devices(n)
+    fi, label, parse_s = load_workload(api, args.workload, args.width, args.height, args.maxdepth)
+    depth = fi.max_recursion_depth if args.maxdepth < 0 else args.maxdepth
+    cam = fi.camera()
+    t0 = time.perf_counter()
+    scene = api.Scene(fi.scene_desc)
+    scene_create_s = time.perf_counter() - t0
+    prm = fi.params(max_bounce_count=depth)
+    for _ in range(args.warmup):
+        api.render_multi(scene, cam, prm, n)
+    t0 = time.perf_counter()
+    frames = [api.render_multi(scene, cam, prm, n) for _ in range(args.steps)]      # each call returns with the image on the host
+    elapsed = time.perf_counter() - t0
+    rays = float(sum(st.closest_rays + st.shadow_rays for f in frames for st in f["stats"]))
+    per_device_ms = [sum(f["stats"][d].device_ms for f in frames) / args.steps for d in range(n)]
+    out = {"metric": "Mrays/s", "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic" if args.workload == "synthetic" else "reference scene file (tests/golden/scenes), size overridden",
+           "config": {"workload": label, "maxdepth": depth, "samples_per_pixel": 16, "parallelism": "tiles%%%d" % n,
+                      "exchange": "one process, rt_render_multi: RCCL grouped send/receive to device 0, image copied to the host inside every step"},
+           "per_device_ms": per_device_ms, "setup_ms": {"parse_scene_file": parse_s * 1e3, "scene_create_all_devices": scene_create_s * 1e3}}
+    alone = api.render_multi(scene, cam, fi.params(max_bounce_count=depth, rect_x0=0, rect_y0=0, rect_w=fi.width, rect_h=min(fi.height, 256)), n)
+    out["top_rows_identical_to_last_frame"] = bool((alone["rgb"] == frames[-1]["rgb"][:alone["rgb"].shape[0]]).all()) if frames else None
+    scene.close()
+    sys.stdout.flush()
+    os.write(results_fd, (json.dumps(out) + "\n").encode())
 
 
 def brute_force_leg(abi, fi, cam, scene, depth, args, label):

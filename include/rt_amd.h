@@ -194,6 +194,29 @@ uint32_t rt_total_tile_count(const rt_render_params* params);
 int rt_assemble_tiles_device(const void* gathered_tiles_dev, uint32_t tiles_per_rank_stride,
                              const rt_render_params* params, void* rgb_dev);
 
+/* ---- more than one GPU -----------------------------------------------------------
+ * The reference hands scanlines to the threads of one machine (Source/render_work_queue.cpp:59-80, Source/main.cpp:77-90).
+ * Here tile t of the rectangle belongs to GPU t % n, the scene is replicated, and the only exchange is every GPU sending
+ * its compact tile buffer to the first one over xGMI (RCCL, grouped send / receive), which scatters them into the image.
+ * Two ways to set it up:
+ *  (1) ONE PROCESS, n GPUs: rt_init_devices(n) (devices 0..n-1, one host thread and one set of streams per device, one
+ *      RCCL communicator from ncclCommInitAll); rt_scene_create then replicates the scene on every device, and
+ *      rt_render_multi stands where rt_render does: same image bytes.  stats_per_device: n entries, or null.
+ *  (2) ONE PROCESS PER GPU (rank r renders with tile_rank = r, tile_world = n): rank 0 calls rt_comm_unique_id and hands
+ *      the identifier to the others by any means the host has; every rank calls rt_comm_init_rank after rt_init;
+ *      after rt_render_tiles_device has returned, rt_comm_gather_tiles enqueues the exchange of the tile buffers on a
+ *      stream of its own (gathered_dev, world * stride * 768 bytes, is needed on rank 0 only) and returns at once, so the next
+ *      frame can be traced meanwhile; rt_comm_wait waits for it; rank 0 then calls rt_assemble_tiles_device. */
+#define RT_COMM_ID_BYTES 128
+int rt_init_devices(int n_devices);
+int rt_render_multi(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params,
+                    uint8_t* rgb_out, rt_stats* stats_per_device);
+int rt_comm_unique_id(uint8_t id[RT_COMM_ID_BYTES]);
+int rt_comm_init_rank(const uint8_t id[RT_COMM_ID_BYTES], int rank, int world);
+int rt_comm_gather_tiles(const void* tiles_dev, uint32_t tiles_per_rank_stride, void* gathered_dev);
+int rt_comm_wait(void);
+void rt_comm_destroy(void);
+
 /* ---- front end (host) --------------------------------------------------------*/
 /* parse_input_file (Source/input_parsing.cpp:96-603).  On a parse error returns
  * non-zero and rt_last_error() is the reference's message for that error. */

@@ -117,6 +117,13 @@ PROTOTYPES = {
     "rt_rank_tile_count": (C.c_uint32, [C.POINTER(RenderParams)]),
     "rt_total_tile_count": (C.c_uint32, [C.POINTER(RenderParams)]),
     "rt_assemble_tiles_device": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(RenderParams), C.c_void_p]),
+    "rt_init_devices": (C.c_int, [C.c_int]),
+    "rt_render_multi": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]),
+    "rt_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "rt_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "rt_comm_gather_tiles": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rt_comm_wait": (C.c_int, []),
+    "rt_comm_destroy": (None, []),
     "rt_parse_input_file": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "rt_file_info_destroy": (None, [C.c_void_p]),
     "rt_file_info_scene": (C.POINTER(SceneDesc), [C.c_void_p]),

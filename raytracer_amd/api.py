@@ -146,6 +146,43 @@ def render_tiles_noalloc(scene, camera, params, tiles_dev_ptr):
     _check(lib().rt_render_tiles_noalloc(scene._h, C.byref(camera), C.byref(params), C.c_void_p(tiles_dev_ptr)))
 
 
+def init_devices(n):
+    _check(lib().rt_init_devices(int(n)))
+
+
+def render_multi(scene, camera, params, n_devices):
+    """rt_render_multi: the image of the rectangle traced by all devices of rt_init_devices; returns dict(rgb, stats per device)."""
+    rw = params.rect_w or params.width
+    rh = params.rect_h if params.rect_w else params.height
+    rgb = np.zeros((rh, rw, 3), np.uint8)
+    stats = (abi.Stats * n_devices)()
+    _check(lib().rt_render_multi(scene._h, C.byref(camera), C.byref(params), rgb.ctypes.data, stats))
+    return {"rgb": rgb, "stats": list(stats)}
+
+
+def comm_unique_id():
+    buf = (C.c_uint8 * 128)()
+    _check(lib().rt_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def comm_init_rank(unique_id, rank, world):
+    buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+    _check(lib().rt_comm_init_rank(buf, int(rank), int(world)))
+
+
+def comm_gather_tiles(tiles_ptr, tiles_per_rank_stride, gathered_ptr):
+    _check(lib().rt_comm_gather_tiles(C.c_void_p(tiles_ptr), tiles_per_rank_stride, C.c_void_p(gathered_ptr) if gathered_ptr else None))
+
+
+def comm_wait():
+    _check(lib().rt_comm_wait())
+
+
+def comm_destroy():
+    lib().rt_comm_destroy()
+
+
 def rank_tile_count(params):
     return lib().rt_rank_tile_count(C.byref(params))
 

@@ -26,6 +26,8 @@
 // __builtin_fmaf calls, in the reference's operand order.  Division and square root are
 // the correctly rounded ones (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library itself is loaded on first use (load_rccl)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -2419,8 +2421,35 @@ struct Library {
     unsigned char* scratch = nullptr;       // device address of `scratch` on this device (hipGetSymbolAddress)
     std::mutex guard;                       // one call at a time uses the lanes, the arenas and the counters
     std::vector<hipEvent_t> events;
+    // multi-GPU (rt_comm_*, rt_init_devices): this device's rank in a communicator, a stream for the exchange, tile buffers
+    void* comm = nullptr;                   // ncclComm_t
+    int comm_rank = 0, comm_world = 1;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t comm_ready = nullptr;        // the tiles to send are complete
+    uint8_t* multi_tiles = nullptr;         // rt_render_multi: this device's tile buffer, and on device 0 the gathered buffers and the image
+    uint8_t* multi_gathered = nullptr;
+    uint8_t* multi_image = nullptr;
+    size_t multi_tiles_bytes = 0, multi_gathered_bytes = 0, multi_image_bytes = 0;
 };
-Library g_lib;
+// One context per HIP device.  A process that renders on one GPU (rt_init) has one; rt_init_devices creates one per
+// device of a single process.  Calls use the context their thread was bound to (bind_device), or the first one created.
+constexpr int MAX_DEVICES = 16;
+Library g_devices[MAX_DEVICES];
+std::atomic<Library*> g_first_device{nullptr};
+std::atomic<int> g_multi_devices{0};        // > 0: rt_init_devices was called with this many devices
+thread_local Library* t_device = nullptr;
+Library& current_device() {
+    if (t_device) return *t_device;
+    Library* first = g_first_device.load(std::memory_order_acquire);
+    return first ? *first : g_devices[0];
+}
+// Binds the calling thread to a device context (and makes its HIP device current) for the life of the object.
+struct DeviceBinding {
+    Library* before;
+    bool ok;
+    explicit DeviceBinding(Library& lib) : before(t_device), ok(hipSetDevice(lib.device) == hipSuccess) { t_device = &lib; }
+    ~DeviceBinding() { t_device = before; if (before) (void)hipSetDevice(before->device); }
+};
 
 #ifndef RT_RAYS_PER_LANE
 #define RT_RAYS_PER_LANE 2
@@ -2486,6 +2515,8 @@ uint32_t rank_tiles(const rt_render_params& p) {
 
 struct rt_scene {
     DevScene dev;
+    int device = -1;                   // the HIP device these allocations live on
+    rt_scene* next = nullptr;          // the replica on the next device of a single-process multi-GPU set-up (rt_init_devices)
     std::vector<void*> allocations;
     // bound of ray origins the box records were built for; grows (records rebuilt) when a camera's eye lies outside it:
     // one render at a time per scene
@@ -2502,7 +2533,7 @@ constexpr size_t state_bytes(size_t samples) { return samples * 35 * sizeof(floa
 
 // Scratch of rt_render_tiles_noalloc: the per-sample state of one chunk of at most NOALLOC_MAX_TILES tiles, then 64 list
 // lengths, then the work counters.  Device code and host code reach it only through the address
-// rt_init obtains with hipGetSymbolAddress (g_lib.scratch): the name below is not a device address on the host side.
+// rt_init obtains with hipGetSymbolAddress (Library::scratch): the name below is not a device address on the host side.
 constexpr uint32_t NOALLOC_MAX_TILES = RT_NOALLOC_MAX_TILES;
 constexpr size_t NOALLOC_STATE_BYTES = (state_bytes(static_cast<size_t>(NOALLOC_MAX_TILES) * SAMPLES_PER_TILE) + 255) / 256 * 256;
 constexpr size_t NOALLOC_COUNTS_BYTES = 256;                                      // 64 words
@@ -2544,15 +2575,16 @@ struct Timer {
     // families: 0 closest-hit scans of a bounce (all kinds), 1 shadow scans of a light group (all kinds),
     // 2 + kind: one kind's closest-hit scan, 5 + kind: one kind's shadow scan (kind: 0 triangles, 1 spheres, 2 ellipsoids)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans[8];
+    Library* owner = nullptr;    // whose pool of events is used
     size_t next_event = 0;
     std::mutex guard;   // the lanes of a frame are driven by a host thread each
     hipEvent_t take() {
-        if (next_event == g_lib.events.size()) {
+        if (next_event == owner->events.size()) {
             hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) return nullptr;
-            g_lib.events.push_back(e);
+            owner->events.push_back(e);
         }
-        return g_lib.events[next_event++];
+        return owner->events[next_event++];
     }
 };
 
@@ -2617,8 +2649,9 @@ void launch_shadow_scan(bool deep, dim3 grid, hipStream_t on, const DevScene& sc
 
 int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_render_params* prm, uint8_t* tiles_dev,
                 uint32_t* ids_dev /* rect-shaped, nullable */, rt_stats* stats, bool no_alloc = false) {
-    if (!g_lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
-    std::lock_guard<std::mutex> one_at_a_time(g_lib.guard);
+    Library& lib = current_device();
+    if (!lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    std::lock_guard<std::mutex> one_at_a_time(lib.guard);
     if (!scene || !cam || !prm) return rt_fail(RT_ERR_ARGUMENT, "null argument");
     if (prm->width == 0 || prm->height == 0) return rt_fail(RT_ERR_ARGUMENT, "image size is zero");
     if (prm->max_bounce_count < 0 || static_cast<uint32_t>(prm->max_bounce_count) > MAX_BOUNCES) return rt_fail(RT_ERR_LIMIT, "max_bounce_count out of range (0..62)");
@@ -2639,12 +2672,14 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     }
     const size_t chunk_samples = static_cast<size_t>(chunk_tiles) * SAMPLES_PER_TILE;
     const uint32_t n_lanes = std::min(MAX_LANES, ceil_div(my_tiles, chunk_tiles));
-    if (!no_alloc) for (uint32_t l = 0; l < n_lanes; ++l) if (int rc = ensure_state(g_lib.lanes[l], chunk_samples)) return rc;
-    unsigned long long* const stats_dev = no_alloc ? reinterpret_cast<unsigned long long*>(g_lib.scratch + NOALLOC_STATE_BYTES + NOALLOC_COUNTS_BYTES) : g_lib.stats;
-    auto counts_of = [&](uint32_t l) { return no_alloc ? reinterpret_cast<uint32_t*>(g_lib.scratch + NOALLOC_STATE_BYTES) : g_lib.lanes[l].counts; };
+    if (!no_alloc) for (uint32_t l = 0; l < n_lanes; ++l) if (int rc = ensure_state(lib.lanes[l], chunk_samples)) return rc;
+    unsigned long long* const stats_dev = no_alloc ? reinterpret_cast<unsigned long long*>(lib.scratch + NOALLOC_STATE_BYTES + NOALLOC_COUNTS_BYTES) : lib.stats;
+    auto counts_of = [&](uint32_t l) { return no_alloc ? reinterpret_cast<uint32_t*>(lib.scratch + NOALLOC_STATE_BYTES) : lib.lanes[l].counts; };
 
+    while (scene && scene->device != lib.device) scene = scene->next;   // the replica on this device
+    if (!scene) return rt_fail(RT_ERR_ARGUMENT, "the scene has no replica on this device");
     DevScene sc = scene->dev;
-    hipStream_t stream = g_lib.stream;
+    hipStream_t stream = lib.stream;
     {   // the box records must hold for the eye as an origin too
         float need = sc.origin_bound;
         for (int i = 0; i < 3; ++i) need = std::fmax(need, 1.001f * std::fabs(cam->eye[i]) + 1.0e-3f);
@@ -2668,10 +2703,11 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
 
     State lane_state[MAX_LANES];
     for (uint32_t l = 0; l < n_lanes; ++l)
-        lane_state[l] = make_state(no_alloc ? static_cast<void*>(g_lib.scratch) : g_lib.lanes[l].state_mem, counts_of(l), stats_dev, chunk_samples, ids_dev != nullptr);
+        lane_state[l] = make_state(no_alloc ? static_cast<void*>(lib.scratch) : lib.lanes[l].state_mem, counts_of(l), stats_dev, chunk_samples, ids_dev != nullptr);
     HIP_TRY(hipMemsetAsync(stats_dev, 0, STAT_COPIES * ST_COUNT * sizeof(unsigned long long), stream));
 
     Timer timer_storage;
+    timer_storage.owner = &lib;
     Timer* timer = stats ? &timer_storage : nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     if (timer) { ev_begin = timer->take(); ev_end = timer->take(); if (ev_begin) HIP_TRY(hipEventRecord(ev_begin, stream)); }
@@ -2684,8 +2720,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     const bool force_deep = (prm->flags & RT_FLAG_DEEP_WALK) != 0;
     const bool walk[3] = {filter && sc.th.n > below, filter && sc.eh.n > below, filter && sc.sh.n > below};
     if (n_lanes > 1) {   // the other lanes start when the box records and the cleared counters are ready
-        HIP_TRY(hipEventRecord(g_lib.lanes_fork, g_lib.lanes[0].stream));
-        for (uint32_t l = 1; l < n_lanes; ++l) HIP_TRY(hipStreamWaitEvent(g_lib.lanes[l].stream, g_lib.lanes_fork, 0));
+        HIP_TRY(hipEventRecord(lib.lanes_fork, lib.lanes[0].stream));
+        for (uint32_t l = 1; l < n_lanes; ++l) HIP_TRY(hipStreamWaitEvent(lib.lanes[l].stream, lib.lanes_fork, 0));
     }
     // One chunk; every launch of it goes to the streams of its lane.
     // The lanes start one after the other: lane l + 1 begins when lane l has generated its rays, so that
@@ -2693,11 +2729,11 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     // starting it after the first scans of lane l gains nothing).
     std::atomic<uint32_t> started_count{0};   // lanes that have recorded (or given up recording) their lanes_started event
     auto run_chunk = [&](uint32_t first, uint32_t chunk) -> int {
-        Lane& lane = g_lib.lanes[chunk % n_lanes];
+        Lane& lane = lib.lanes[chunk % n_lanes];
         const hipStream_t stream = lane.stream;       // everything of this chunk goes to its lane
         if (chunk > 0 && chunk < n_lanes) {
             while (started_count.load(std::memory_order_acquire) < chunk) std::this_thread::yield();   // the event must have been recorded
-            HIP_TRY(hipStreamWaitEvent(stream, g_lib.lanes_started[chunk - 1], 0));
+            HIP_TRY(hipStreamWaitEvent(stream, lib.lanes_started[chunk - 1], 0));
         }
         const State st = lane_state[chunk % n_lanes];
         const uint32_t n_tiles = (my_tiles - first < chunk_tiles) ? my_tiles - first : chunk_tiles;
@@ -2730,7 +2766,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         };
         if (int rc = fetch_count(0)) return rc;
         if (chunk + 1 < n_lanes) {
-            const hipError_t recorded = hipEventRecord(g_lib.lanes_started[chunk], stream);
+            const hipError_t recorded = hipEventRecord(lib.lanes_started[chunk], stream);
             started_count.store(chunk + 1, std::memory_order_release);   // whatever happened: the next lane's thread is waiting for this
             HIP_TRY(recorded);
         }
@@ -2878,7 +2914,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         std::vector<std::thread> helpers;
         for (uint32_t l = 1; l < n_lanes; ++l)
             helpers.emplace_back([&, l] {
-                lane_rc[l] = hipSetDevice(g_lib.device) == hipSuccess ? run_lane(l) : rt_fail(RT_ERR_DEVICE, "hipSetDevice failed in the thread of a lane");
+                DeviceBinding bound(lib);
+                lane_rc[l] = bound.ok ? run_lane(l) : rt_fail(RT_ERR_DEVICE, "hipSetDevice failed in the thread of a lane");
                 if (lane_rc[l]) lane_error[l] = g_last_error;   // the message is per thread
             });
         lane_rc[0] = run_lane(0);
@@ -2892,8 +2929,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         return rt_fail(lane_rc[l], lane_error[l].c_str());
     }
     for (uint32_t l = 1; l < n_lanes; ++l) {
-        HIP_TRY(hipEventRecord(g_lib.lanes_join[l], g_lib.lanes[l].stream));
-        HIP_TRY(hipStreamWaitEvent(stream, g_lib.lanes_join[l], 0));
+        HIP_TRY(hipEventRecord(lib.lanes_join[l], lib.lanes[l].stream));
+        HIP_TRY(hipStreamWaitEvent(stream, lib.lanes_join[l], 0));
     }
     if (timer && ev_end) HIP_TRY(hipEventRecord(ev_end, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -3146,7 +3183,7 @@ int upload(rt_scene* s, const T* host, size_t count, T** dev) {
     if (count == 0) return 0;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(dev), count * sizeof(T)));
     s->allocations.push_back(*dev);
-    if (host) HIP_TRY(hipMemcpyAsync(*dev, host, count * sizeof(T), hipMemcpyHostToDevice, g_lib.stream));
+    if (host) HIP_TRY(hipMemcpyAsync(*dev, host, count * sizeof(T), hipMemcpyHostToDevice, current_device().stream));
     return 0;
 }
 
@@ -3179,48 +3216,88 @@ int rt_device_count(void) {
     return n;
 }
 
-int rt_init(int device) {
-    if (g_lib.ready && g_lib.device == device) return 0;
-    if (g_lib.ready) return rt_fail(RT_ERR_ARGUMENT, "rt_init: already initialised on another device");
+// Creates the context of one device (streams, events, counters); idempotent.
+static int init_device(int device) {
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
-    if (device < 0 || device >= n) return rt_fail(RT_ERR_ARGUMENT, "rt_init: no such device");
+    if (device < 0 || device >= n || device >= MAX_DEVICES) return rt_fail(RT_ERR_ARGUMENT, "rt_init: no such device");
+    Library& lib = g_devices[device];
+    if (lib.ready) return 0;
     HIP_TRY(hipSetDevice(device));
-    for (Lane& lane : g_lib.lanes) {
+    for (Lane& lane : lib.lanes) {
         HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&lane.side_stream, hipStreamNonBlocking));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&lane.counts), 64 * sizeof(uint32_t)));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&lane.host_counts), 64 * sizeof(uint32_t), hipHostMallocDefault));
         HIP_TRY(hipEventCreateWithFlags(&lane.count_ready, hipEventDisableTiming));
     }
-    g_lib.stream = g_lib.lanes[0].stream;
-    HIP_TRY(hipEventCreateWithFlags(&g_lib.lanes_fork, hipEventDisableTiming));
-    for (hipEvent_t& e : g_lib.lanes_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (hipEvent_t& e : g_lib.lanes_started) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_lib.stats), STAT_COPIES * ST_COUNT * sizeof(unsigned long long)));
+    lib.stream = lib.lanes[0].stream;
+    HIP_TRY(hipEventCreateWithFlags(&lib.lanes_fork, hipEventDisableTiming));
+    for (hipEvent_t& e : lib.lanes_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t& e : lib.lanes_started) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&lib.comm_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&lib.comm_ready, hipEventDisableTiming));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&lib.stats), STAT_COPIES * ST_COUNT * sizeof(unsigned long long)));
     // this device's copy of the scratch array of rt_render_tiles_noalloc: its address, once, with the device current
-    HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&g_lib.scratch), HIP_SYMBOL(scratch)));
-    if (!g_lib.scratch) return rt_fail(RT_ERR_DEVICE, "rt_init: the scratch array has no device address");
-    g_lib.device = device;
-    g_lib.ready = true;
+    HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&lib.scratch), HIP_SYMBOL(scratch)));
+    if (!lib.scratch) return rt_fail(RT_ERR_DEVICE, "rt_init: the scratch array has no device address");
+    lib.device = device;
+    lib.ready = true;
+    Library* none = nullptr;
+    g_first_device.compare_exchange_strong(none, &lib);
     return 0;
 }
 
-void rt_scene_destroy(rt_scene* scene) {
-    if (!scene) return;
-    for (void* p : scene->allocations) (void)hipFree(p);
-    delete scene;
+int rt_init(int device) {
+    Library* first = g_first_device.load(std::memory_order_acquire);
+    if (first && first->device == device) return 0;
+    if (first) return rt_fail(RT_ERR_ARGUMENT, "rt_init: already initialised on another device");
+    return init_device(device);
 }
 
-static int scene_create_impl(const rt_scene_desc* desc, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene) {
+    while (scene) {
+        rt_scene* next = scene->next;
+        if (scene->device >= 0 && scene->device < MAX_DEVICES && g_devices[scene->device].ready) {
+            DeviceBinding bound(g_devices[scene->device]);
+            for (void* p : scene->allocations) (void)hipFree(p);
+        }
+        delete scene;
+        scene = next;
+    }
+}
+
+// cluster orders of the three kinds (host work, the same for every device)
+struct SceneOrders { std::vector<uint32_t> of[3]; bool ready[3] = {false, false, false}; };
+static int scene_create_impl(const rt_scene_desc* desc, SceneOrders& orders, rt_scene** out);
 int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
-    if (!g_lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    if (!current_device().ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
     if (!desc || !out) return rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: null argument");
     *out = nullptr;
-    std::lock_guard<std::mutex> one_at_a_time(g_lib.guard);
-    return guarded([&] { return scene_create_impl(desc, out); });
+    return guarded([&] {
+        SceneOrders orders;
+        const int n_multi = g_multi_devices.load();
+        if (n_multi <= 1) {
+            Library& lib = current_device();
+            std::lock_guard<std::mutex> one_at_a_time(lib.guard);
+            return scene_create_impl(desc, orders, out);
+        }
+        // one replica per device, device 0 first; the cluster orders are computed once
+        rt_scene* head = nullptr;
+        rt_scene** tail = &head;
+        for (int d = 0; d < n_multi; ++d) {
+            DeviceBinding bound(g_devices[d]);
+            std::lock_guard<std::mutex> one_at_a_time(g_devices[d].guard);
+            const int rc = bound.ok ? scene_create_impl(desc, orders, tail) : rt_fail(RT_ERR_DEVICE, "rt_scene_create: hipSetDevice failed");
+            if (rc) { rt_scene_destroy(head); return rc; }
+            tail = &(*tail)->next;
+        }
+        *out = head;
+        return 0;
+    });
 }
-static int scene_create_impl(const rt_scene_desc* desc, rt_scene** out) {
+static int scene_create_impl(const rt_scene_desc* desc, SceneOrders& orders, rt_scene** out) {
+    Library& lib = current_device();
     if (desc->n_point_lights && !desc->point_light_sources) return rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: point_light_sources is null");
     if ((desc->n_triangles && !desc->triangle_materials) || (desc->n_spheres && !desc->sphere_materials) || (desc->n_ellipsoids && !desc->ellipsoid_materials))
         return rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: a material array is null");
@@ -3229,10 +3306,11 @@ static int scene_create_impl(const rt_scene_desc* desc, rt_scene** out) {
     if (desc->n_point_lights > 4096) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 4096 point lights");
     if (desc->n_triangle8 > (1u << 21) || desc->n_sphere8 > (1u << 21) || desc->n_ellipsoid8 > (1u << 21)) return rt_fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^24 slots of one primitive kind");
     rt_scene* s = new rt_scene();
+    s->device = lib.device;
     auto fail = [&](int rc) { rt_scene_destroy(s); return rc; };
     DevScene& d = s->dev;
     std::memset(&d, 0, sizeof d);
-    hipStream_t stream = g_lib.stream;
+    hipStream_t stream = lib.stream;
     int rc;
 
     d.tri_nb = static_cast<uint32_t>(desc->n_triangle8); d.n_tri = 8u * d.tri_nb;
@@ -3273,7 +3351,6 @@ static int scene_create_impl(const rt_scene_desc* desc, rt_scene** out) {
         hipLaunchKernelGGL(k_prep_ellipsoid_lights, dim3(ceil_div(d.n_ell, BLOCK)), dim3(BLOCK), 0, stream, ell, d.n_ell, raw_pl, static_cast<uint32_t>(desc->n_point_lights), ell_light);
 
     // box hierarchy of every kind (see Hierarchy): cluster order on the host; the boxes themselves by build_boxes below
-    std::vector<uint32_t> orders[3];   // stay alive until the stream has been synchronised below
     for (int prim = 0; prim < 3; ++prim) {
         Hierarchy& h = prim == 0 ? d.th : (prim == 1 ? d.eh : d.sh);
         h.n = prim == 0 ? d.n_tri : (prim == 1 ? d.n_ell : d.n_sph);
@@ -3281,23 +3358,26 @@ static int scene_create_impl(const rt_scene_desc* desc, rt_scene** out) {
         h.n_tops = ceil_div(h.n_clusters, CLUSTER);
         h.n_supers = ceil_div(h.n_tops, CLUSTER);
         if (h.n == 0) continue;
-        std::vector<float> centroid, bounds;
-        std::vector<uint8_t> good;
-        if (prim == 0) {
-            if (!desc->triangle8s) return fail(rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: triangle8s is null"));
-            triangle_centroids(desc->triangle8s, d.tri_nb, centroid, bounds, good);
-        } else if (prim == 1) {
-            if (!desc->ellipsoid8_transforms || !desc->ellipsoid8_inverse_transforms) return fail(rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: ellipsoid transforms are null"));
-            ellipsoid_centroids(desc->ellipsoid8_transforms, desc->ellipsoid8_inverse_transforms, d.ell_nb, centroid, bounds, good);
-        } else {
-            if (!desc->sphere8s) return fail(rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: sphere8s is null"));
-            sphere_centroids(desc->sphere8s, d.sph_nb, centroid, bounds, good);
+        if (!orders.ready[prim]) {
+            std::vector<float> centroid, bounds;
+            std::vector<uint8_t> good;
+            if (prim == 0) {
+                if (!desc->triangle8s) return fail(rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: triangle8s is null"));
+                triangle_centroids(desc->triangle8s, d.tri_nb, centroid, bounds, good);
+            } else if (prim == 1) {
+                if (!desc->ellipsoid8_transforms || !desc->ellipsoid8_inverse_transforms) return fail(rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: ellipsoid transforms are null"));
+                ellipsoid_centroids(desc->ellipsoid8_transforms, desc->ellipsoid8_inverse_transforms, d.ell_nb, centroid, bounds, good);
+            } else {
+                if (!desc->sphere8s) return fail(rt_fail(RT_ERR_ARGUMENT, "rt_scene_create: sphere8s is null"));
+                sphere_centroids(desc->sphere8s, d.sph_nb, centroid, bounds, good);
+            }
+            orders.of[prim] = cluster_order(centroid, bounds, good);
+            orders.ready[prim] = true;
         }
-        orders[prim] = cluster_order(centroid, bounds, good);
         uint32_t* k_of;
         float4 *leaf_box, *cl_box, *top_box, *super_box;
         uint4 *cl_nodes, *top_nodes, *super_nodes;
-        if ((rc = upload(s, orders[prim].data(), orders[prim].size(), &k_of))) return fail(rc);
+        if ((rc = upload(s, orders.of[prim].data(), orders.of[prim].size(), &k_of))) return fail(rc);
         if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n) * 2, &leaf_box))) return fail(rc);
         if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n_clusters) * 2, &cl_box))) return fail(rc);
         if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(h.n_tops) * 2, &top_box))) return fail(rc);
@@ -3357,20 +3437,22 @@ int rt_render_tiles_noalloc(const rt_scene* scene, const rt_camera_desc* camera,
 }
 
 int rt_assemble_tiles_device(const void* gathered, uint32_t stride_tiles, const rt_render_params* params, void* rgb_dev) {
-    if (!g_lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
-    std::lock_guard<std::mutex> one_at_a_time(g_lib.guard);
+    Library& lib = current_device();
+    if (!lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    std::lock_guard<std::mutex> one_at_a_time(lib.guard);
     if (!gathered || !params || !rgb_dev) return rt_fail(RT_ERR_ARGUMENT, "rt_assemble_tiles_device: null argument");
     const Rect rect = rect_of(*params);
     const uint32_t world = params->tile_world ? params->tile_world : 1;
-    hipLaunchKernelGGL(k_assemble, dim3(ceil_div(rect.w * rect.h, BLOCK)), dim3(BLOCK), 0, g_lib.stream,
+    hipLaunchKernelGGL(k_assemble, dim3(ceil_div(rect.w * rect.h, BLOCK)), dim3(BLOCK), 0, lib.stream,
                        static_cast<const uint8_t*>(gathered), stride_tiles, world, rect.w, rect.h, rect.tiles_x, static_cast<uint8_t*>(rgb_dev));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(g_lib.stream));
+    HIP_TRY(hipStreamSynchronize(lib.stream));
     return 0;
 }
 
 int rt_render(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params, uint8_t* rgb_out, uint32_t* primary_id_out, rt_stats* stats) {
-    if (!g_lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    Library& lib = current_device();
+    if (!lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
     if (!params || !rgb_out) return rt_fail(RT_ERR_ARGUMENT, "rt_render: null argument");
     const Rect rect = rect_of(*params);
     const uint32_t world = params->tile_world ? params->tile_world : 1;
@@ -3386,7 +3468,7 @@ int rt_render(const rt_scene* scene, const rt_camera_desc* camera, const rt_rend
         cleanup();
         return rt_fail(RT_ERR_DEVICE, "rt_render: out of device memory");
     }
-    if (primary_id_out && hipMemsetAsync(ids_dev, 0xFF, n_px * 16 * sizeof(uint32_t), g_lib.stream) != hipSuccess) { cleanup(); return rt_fail(RT_ERR_DEVICE, "rt_render: memset failed"); }
+    if (primary_id_out && hipMemsetAsync(ids_dev, 0xFF, n_px * 16 * sizeof(uint32_t), lib.stream) != hipSuccess) { cleanup(); return rt_fail(RT_ERR_DEVICE, "rt_render: memset failed"); }
     rc = guarded([&] { return render_impl(scene, camera, params, tiles_dev, ids_dev, stats); });
     if (rc == 0) {
         if (world == 1) {
@@ -3428,7 +3510,8 @@ int rt_render_file_info(const rt_file_info* info, uint8_t* rgb_out, rt_stats* st
 }
 
 int rt_debug_eval(int op, uint32_t n, const float* a, const float* b, float* out) {
-    if (!g_lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    Library& lib = current_device();
+    if (!lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
     static const struct { int op; uint32_t a_per_item, a_fixed, b_per_item, out_per_item; } shapes[] = {
         {RT_DEBUG_FP_POW, 1, 0, 1, 1}, {RT_DEBUG_FP_MIN, 1, 0, 1, 1}, {RT_DEBUG_FP_MAX, 1, 0, 1, 1}, {RT_DEBUG_DIVIDE, 1, 0, 1, 1},
         {RT_DEBUG_DIVIDE_IN_RANGE, 1, 0, 1, 1}, {RT_DEBUG_PRIMARY_RAY, 0, 16, 4, 3}, {RT_DEBUG_SCENE_BOX, 0, 6, 6, 2},
@@ -3442,7 +3525,7 @@ int rt_debug_eval(int op, uint32_t n, const float* a, const float* b, float* out
     float* dev = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), (na + nb + no) * sizeof(float)));
     int rc = 0;
-    hipStream_t stream = g_lib.stream;
+    hipStream_t stream = lib.stream;
     if (hipMemcpyAsync(dev, a, na * sizeof(float), hipMemcpyHostToDevice, stream) != hipSuccess ||
         hipMemcpyAsync(dev + na, b, nb * sizeof(float), hipMemcpyHostToDevice, stream) != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_debug_eval: upload failed");
     if (rc == 0) {
@@ -3452,6 +3535,231 @@ int rt_debug_eval(int op, uint32_t n, const float* a, const float* b, float* out
     }
     (void)hipFree(dev);
     return rc;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// multi-GPU: image tiles over devices, tile buffers gathered on the first one by RCCL (xGMI)
+// ------------------------------------------------------------------------------------------
+// This stands where the reference hands scanlines to the threads of one machine
+// (Source/render_work_queue.cpp:59-80, Source/main.cpp:77-90): tile t of the rectangle belongs to device
+// t % n, the scene is replicated, and the only exchange is every device sending its compact tile buffer to
+// the first device (grouped ncclSend / ncclRecv: one hop per peer over xGMI), which scatters the tiles into
+// the row-major image (k_assemble).  RCCL is loaded on first use, so hosts that render on one GPU never load it.
+namespace {
+
+struct Rccl {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+Rccl g_rccl;
+std::mutex g_rccl_guard;
+
+int load_rccl() {
+    std::lock_guard<std::mutex> lock(g_rccl_guard);
+    if (g_rccl.ok) return 0;
+    // a copy the process has loaded already (a host that brings its own ROCm libraries) comes first
+    void* handle = nullptr;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* name : names) if (!handle) handle = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    for (const char* name : names) if (!handle) handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (!handle) return rt_fail(RT_ERR_DEVICE, "RCCL (librccl.so) could not be loaded");
+    auto sym = [&](const char* name) { return dlsym(handle, name); };
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(sym("ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(sym("ncclCommInitRank"));
+    g_rccl.CommInitAll = reinterpret_cast<decltype(g_rccl.CommInitAll)>(sym("ncclCommInitAll"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(sym("ncclCommDestroy"));
+    g_rccl.Send = reinterpret_cast<decltype(g_rccl.Send)>(sym("ncclSend"));
+    g_rccl.Recv = reinterpret_cast<decltype(g_rccl.Recv)>(sym("ncclRecv"));
+    g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(sym("ncclGroupStart"));
+    g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(sym("ncclGroupEnd"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.Send || !g_rccl.Recv ||
+        !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.GetErrorString) return rt_fail(RT_ERR_DEVICE, "RCCL lacks an entry point this library needs");
+    g_rccl.ok = true;
+    return 0;
+}
+
+#define RCCL_TRY(expr)                                                                        \
+    do {                                                                                      \
+        ncclResult_t r_ = (expr);                                                             \
+        if (r_ != ncclSuccess) {                                                              \
+            char buf_[512];                                                                   \
+            std::snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+            return rt_fail(RT_ERR_DEVICE, buf_);                                              \
+        }                                                                                     \
+    } while (0)
+
+// Every device of `devices` sends `bytes` bytes of its tile buffer to the first one, which receives them rank-major
+// (its own included: a send to itself, so that one device alone exercises the same calls).  Enqueued on the
+// devices' exchange streams; the caller synchronises the first device's stream.
+int enqueue_gather(Library* const* devices, const uint8_t* const* send, int n, size_t bytes, uint8_t* gathered_on_first, int only_rank = -1) {
+    RCCL_TRY(g_rccl.GroupStart());
+    for (int d = 0; d < n; ++d) {
+        if (only_rank >= 0 && d != only_rank) continue;     // one process per GPU: this process issues its own rank's part
+        Library& lib = *devices[d];
+        const ncclComm_t comm = static_cast<ncclComm_t>(lib.comm);
+        if (bytes) RCCL_TRY(g_rccl.Send(send[d], bytes, ncclUint8, 0, comm, lib.comm_stream));
+        if (lib.comm_rank == 0 && bytes)
+            for (int r = 0; r < lib.comm_world; ++r) RCCL_TRY(g_rccl.Recv(gathered_on_first + static_cast<size_t>(r) * bytes, bytes, ncclUint8, r, comm, lib.comm_stream));
+    }
+    RCCL_TRY(g_rccl.GroupEnd());
+    return 0;
+}
+
+int grow(uint8_t** buffer, size_t* have, size_t need) {
+    if (*have >= need) return 0;
+    if (*buffer) { HIP_TRY(hipFree(*buffer)); *buffer = nullptr; *have = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(buffer), need));
+    *have = need;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_comm_unique_id(uint8_t id[RT_COMM_ID_BYTES]) {
+    static_assert(RT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the identifier is RCCL's");
+    if (!id) return rt_fail(RT_ERR_ARGUMENT, "rt_comm_unique_id: null argument");
+    if (int rc = load_rccl()) return rc;
+    ncclUniqueId uid;
+    RCCL_TRY(g_rccl.GetUniqueId(&uid));
+    std::memcpy(id, uid.internal, RT_COMM_ID_BYTES);
+    return 0;
+}
+
+int rt_comm_init_rank(const uint8_t id[RT_COMM_ID_BYTES], int rank, int world) {
+    Library& lib = current_device();
+    if (!lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    if (!id || world < 1 || rank < 0 || rank >= world) return rt_fail(RT_ERR_ARGUMENT, "rt_comm_init_rank: bad rank / world / identifier");
+    if (lib.comm) return rt_fail(RT_ERR_ARGUMENT, "rt_comm_init_rank: this device already belongs to a communicator");
+    if (int rc = load_rccl()) return rc;
+    HIP_TRY(hipSetDevice(lib.device));
+    ncclUniqueId uid;
+    std::memcpy(uid.internal, id, RT_COMM_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(g_rccl.CommInitRank(&comm, world, uid, rank));
+    lib.comm = comm; lib.comm_rank = rank; lib.comm_world = world;
+    return 0;
+}
+
+int rt_comm_gather_tiles(const void* tiles_dev, uint32_t tiles_per_rank_stride, void* gathered_dev) {
+    Library& lib = current_device();
+    if (!lib.ready || !lib.comm) return rt_fail(RT_ERR_DEVICE, "rt_comm_gather_tiles: no communicator (rt_comm_init_rank)");
+    if (!tiles_dev || (lib.comm_rank == 0 && !gathered_dev)) return rt_fail(RT_ERR_ARGUMENT, "rt_comm_gather_tiles: null buffer");
+    Library* devices[MAX_DEVICES] = {};
+    const uint8_t* send[MAX_DEVICES] = {};
+    devices[lib.comm_rank % MAX_DEVICES] = &lib;          // only this rank's entry is used
+    send[lib.comm_rank % MAX_DEVICES] = static_cast<const uint8_t*>(tiles_dev);
+    if (lib.comm_world > MAX_DEVICES) return rt_fail(RT_ERR_LIMIT, "rt_comm_gather_tiles: more ranks than this library supports");
+    return enqueue_gather(devices, send, lib.comm_world, static_cast<size_t>(tiles_per_rank_stride) * 768, static_cast<uint8_t*>(gathered_dev), lib.comm_rank);
+}
+
+int rt_comm_wait(void) {
+    Library& lib = current_device();
+    if (!lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    HIP_TRY(hipStreamSynchronize(lib.comm_stream));
+    return 0;
+}
+
+void rt_comm_destroy(void) {
+    for (Library& lib : g_devices) {
+        if (!lib.comm) continue;
+        if (g_rccl.ok) (void)g_rccl.CommDestroy(static_cast<ncclComm_t>(lib.comm));
+        lib.comm = nullptr; lib.comm_rank = 0; lib.comm_world = 1;
+    }
+}
+
+int rt_init_devices(int n_devices) {
+    if (n_devices < 1 || n_devices > MAX_DEVICES) return rt_fail(RT_ERR_ARGUMENT, "rt_init_devices: between 1 and 16 devices");
+    if (g_multi_devices.load() == n_devices) return 0;
+    if (g_multi_devices.load() != 0) return rt_fail(RT_ERR_ARGUMENT, "rt_init_devices: already initialised with another number of devices");
+    Library* first = g_first_device.load(std::memory_order_acquire);
+    if (first && first->device != 0) return rt_fail(RT_ERR_ARGUMENT, "rt_init_devices: rt_init chose a device other than 0 before");
+    for (int d = 0; d < n_devices; ++d) if (int rc = init_device(d)) return rc;
+    HIP_TRY(hipSetDevice(0));
+    if (n_devices > 1 || std::getenv("RT_AMD_COMM_ALWAYS")) {   // one device needs no exchange (the variable makes it go through RCCL all the same: tests)
+        for (int d = 0; d < n_devices; ++d) if (g_devices[d].comm) return rt_fail(RT_ERR_ARGUMENT, "rt_init_devices: a device already belongs to a communicator");
+        if (int rc = load_rccl()) return rc;
+        ncclComm_t comms[MAX_DEVICES];
+        int list[MAX_DEVICES];
+        for (int d = 0; d < n_devices; ++d) list[d] = d;
+        RCCL_TRY(g_rccl.CommInitAll(comms, n_devices, list));
+        for (int d = 0; d < n_devices; ++d) { g_devices[d].comm = comms[d]; g_devices[d].comm_rank = d; g_devices[d].comm_world = n_devices; }
+        HIP_TRY(hipSetDevice(0));
+    }
+    g_multi_devices.store(n_devices);
+    return 0;
+}
+
+int rt_render_multi(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params, uint8_t* rgb_out, rt_stats* stats_per_device) {
+    const int n = g_multi_devices.load();
+    if (n < 1) return rt_fail(RT_ERR_DEVICE, "rt_render_multi: rt_init_devices has not been called");
+    if (!scene || !camera || !params || !rgb_out) return rt_fail(RT_ERR_ARGUMENT, "rt_render_multi: null argument");
+    return guarded([&]() -> int {
+        const Rect rect = rect_of(*params);
+        if (rect.w == 0 || rect.h == 0) return rt_fail(RT_ERR_ARGUMENT, "rt_render_multi: empty rectangle");
+        const uint32_t stride = ceil_div(rect.tiles, static_cast<uint32_t>(n));
+        const size_t bytes = static_cast<size_t>(stride) * 768, image_bytes = static_cast<size_t>(rect.w) * rect.h * 3;
+        // one host thread per device (the caller's takes device 0): its share of the tiles into its tile buffer
+        int rc_of[MAX_DEVICES] = {};
+        std::string error_of[MAX_DEVICES];
+        auto run_device = [&](int d) {
+            Library& lib = g_devices[d];
+            DeviceBinding bound(lib);
+            int rc = bound.ok ? 0 : rt_fail(RT_ERR_DEVICE, "rt_render_multi: hipSetDevice failed");
+            if (!rc) rc = grow(&lib.multi_tiles, &lib.multi_tiles_bytes, bytes);
+            if (!rc && d == 0) rc = grow(&lib.multi_gathered, &lib.multi_gathered_bytes, bytes * n);
+            if (!rc && d == 0) rc = grow(&lib.multi_image, &lib.multi_image_bytes, image_bytes);
+            if (!rc) {
+                rt_render_params mine = *params;
+                mine.tile_rank = static_cast<uint32_t>(d);
+                mine.tile_world = static_cast<uint32_t>(n);
+                rc = render_impl(scene, camera, &mine, lib.multi_tiles, nullptr, stats_per_device ? stats_per_device + d : nullptr);   // returns with the device's streams idle
+            }
+            rc_of[d] = rc;
+            if (rc) error_of[d] = g_last_error;
+        };
+        {
+            std::vector<std::thread> helpers;
+            for (int d = 1; d < n; ++d) helpers.emplace_back(run_device, d);
+            run_device(0);
+            for (std::thread& t : helpers) t.join();
+        }
+        for (int d = 0; d < n; ++d) if (rc_of[d]) return rt_fail(rc_of[d], error_of[d].c_str());
+        Library& root = g_devices[0];
+        DeviceBinding bound(root);
+        const uint8_t* gathered = root.multi_tiles;
+        if (root.comm) {
+            Library* devices[MAX_DEVICES];
+            const uint8_t* send[MAX_DEVICES];
+            for (int d = 0; d < n; ++d) { devices[d] = &g_devices[d]; send[d] = g_devices[d].multi_tiles; }
+            if (int rc = enqueue_gather(devices, send, n, bytes, root.multi_gathered)) return rc;
+            gathered = root.multi_gathered;
+        }
+        rt_render_params whole = *params;
+        whole.tile_rank = 0; whole.tile_world = static_cast<uint32_t>(n);
+        hipLaunchKernelGGL(k_assemble, dim3(ceil_div(rect.w * rect.h, BLOCK)), dim3(BLOCK), 0, root.comm_stream,
+                           gathered, stride, static_cast<uint32_t>(n), rect.w, rect.h, rect.tiles_x, root.multi_image);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(rgb_out, root.multi_image, image_bytes, hipMemcpyDeviceToHost, root.comm_stream));
+        HIP_TRY(hipStreamSynchronize(root.comm_stream));
+        for (int d = 1; d < n; ++d) {      // the senders' streams, so that their tile buffers may be written again
+            DeviceBinding other(g_devices[d]);
+            HIP_TRY(hipStreamSynchronize(g_devices[d].comm_stream));
+        }
+        return 0;
+    });
 }
 
 }  // extern "C"

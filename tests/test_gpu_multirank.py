@@ -35,3 +35,66 @@ def test_split_frames_assemble_to_the_single_rank_frame(gpu, world):
     gpu.assemble_tiles_device(gathered.data_ptr(), stride, fi.params(tile_world=world, **rect), frame.data_ptr())
     assert np.array_equal(frame.cpu().numpy().reshape(whole.shape), whole)
     scene.close()
+
+
+def test_library_communicator_gathers_tile_buffers_through_rccl(gpu):
+    """One process per GPU, as the library sees it (rt_comm_*), with the one GPU a box has: a communicator of one rank, whose
+    gather still goes through RCCL (a send to itself).  Frame assembled from the gathered buffer == frame rendered directly."""
+    import torch
+    from raytracer_amd import distributed
+    fi = gpu.FileInfo(scene_path("scene6"))
+    cam = fi.camera()
+    scene = gpu.Scene(fi.scene_desc)
+    rect = dict(rect_x0=100, rect_y0=80, rect_w=330, rect_h=210)
+    prm = fi.params(tile_rank=0, tile_world=1, **rect)
+    whole = scene.render(cam, prm)["rgb"]
+    uid = gpu.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    gpu.comm_init_rank(uid, 0, 1)
+    try:
+        stride = distributed.stride_tiles(prm, 1)
+        tiles = torch.zeros(stride * 768, dtype=torch.uint8, device="cuda:0")
+        gathered = torch.zeros(stride * 768, dtype=torch.uint8, device="cuda:0")
+        frame = torch.zeros(whole.size, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        for _ in range(2):                      # twice: the exchange stream is reused
+            scene.render_tiles_device(cam, prm, tiles.data_ptr())
+            gpu.comm_gather_tiles(tiles.data_ptr(), stride, gathered.data_ptr())
+            gpu.comm_wait()
+            gpu.assemble_tiles_device(gathered.data_ptr(), stride, prm, frame.data_ptr())
+            assert np.array_equal(frame.cpu().numpy().reshape(whole.shape), whole)
+            gathered.zero_()
+            torch.cuda.synchronize()
+    finally:
+        gpu.comm_destroy()
+        scene.close()
+
+
+MULTI_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+import torch
+from raytracer_amd import api
+api.init_devices(1)
+fi = api.FileInfo(%(scene)r)
+scene = api.Scene(fi.scene_desc)
+prm = fi.params(rect_x0=64, rect_y0=48, rect_w=300, rect_h=200)
+multi = api.render_multi(scene, fi.camera(), prm, 1)
+single = scene.render(fi.camera(), prm)
+assert np.array_equal(multi["rgb"], single["rgb"]) and multi["rgb"].any()
+assert multi["stats"][0].closest_rays == single["stats"].closest_rays and multi["stats"][0].hits == single["stats"].hits
+print("MULTI_OK")
+"""
+
+
+@pytest.mark.parametrize("through_rccl", [False, True])
+def test_single_process_multi_device_entry_point(gpu, through_rccl):
+    """rt_init_devices + rt_render_multi in a process of their own (one device here: the partition, the per-device thread, the
+    assembly and the copy back; with RT_AMD_COMM_ALWAYS also ncclCommInitAll and the grouped send / receive)."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    if through_rccl:
+        env["RT_AMD_COMM_ALWAYS"] = "1"
+    done = subprocess.run([sys.executable, "-c", MULTI_SCRIPT % {"root": ROOT, "scene": scene_path("scene6")}], env=env, capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0 and "MULTI_OK" in done.stdout, done.stdout[-2000:] + done.stderr[-2000:]
