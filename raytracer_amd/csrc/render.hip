@@ -1907,37 +1907,81 @@ DEV ShadowRay make_shadow_ray(const State& st, uint32_t slot, bool point, V3 lv)
     return s;
 }
 
-// Brute-force any-hit over the triangle list toward light first_light + blockIdx.y (see k_closest_tri_brute).
-template <int R, bool STAGED>
+// Brute-force any-hit over the triangle list toward light first_light + blockIdx.y (see k_closest_tri_brute), one ray per lane.
+// A blocked ray needs no further tests, but its lane keeps executing while any ray of its wave is still open, and in a
+// dense scene most rays are blocked somewhere along the list.  Every SHADOW_COMPACT_TILES tiles the workgroup therefore
+// packs its open rays into as few waves as they fill (ray data parked in LDS, ids compacted in order with ballots);
+// waves left without rays only take part in the staging and the barriers.  The result does not depend on which lane
+// tests a ray: "blocked" is an OR over the triangles.
+constexpr uint32_t SHADOW_COMPACT_TILES = 4;
+template <bool STAGED>
 __global__ void __launch_bounds__(BLOCK) k_shadow_tri_brute(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
     __shared__ float4 lds[TILE_PRIMS * 4];
+    __shared__ float4 parked[2][BLOCK];        // (o, limit) (d, -) of the workgroup's rays, by ray number
+    __shared__ uint32_t ray_blocked[BLOCK];    // by ray number
+    __shared__ uint32_t open_ids[BLOCK];       // the open rays' numbers, packed
+    __shared__ uint32_t wave_open[BLOCK / 64];
     const uint32_t n_rays = st.counts[bounce + 1];
-    const uint32_t base = blockIdx.x * (BLOCK * R);
+    const uint32_t base = blockIdx.x * BLOCK;
     if (base >= n_rays) return;
     const float* __restrict__ L = sc.lights + (first_light + blockIdx.y) * 8;
     const uint32_t light_bit = 1u << (first_light + blockIdx.y - group_first);
-    ShadowRays<R> s;
-    load_shadow_rays<R>(st, st.list[(bounce + 1) & 1u], base, n_rays, L[0] != 0.0f, V3{L[1], L[2], L[3]}, light_bit, s);
-    bool tame = true;
-#pragma unroll
-    for (int r = 0; r < R; ++r) tame = tame && ray_is_tame(s.o[r], s.d[r]);
-    const bool staged_wave = __all(tame);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    ShadowRays<1> own;                         // this thread's own ray: number threadIdx.x
+    load_shadow_rays<1>(st, st.list[(bounce + 1) & 1u], base, n_rays, L[0] != 0.0f, V3{L[1], L[2], L[3]}, light_bit, own);
+    parked[0][threadIdx.x] = make_float4(own.o[0].x, own.o[0].y, own.o[0].z, own.limit[0]);
+    parked[1][threadIdx.x] = make_float4(own.d[0].x, own.d[0].y, own.d[0].z, 0.0f);
+    ray_blocked[threadIdx.x] = (own.blocked[0] || !own.valid[0]) ? 1u : 0u;
+    // the ray this lane is testing now: `mine` (a ray number), open while `active`
+    uint32_t mine = threadIdx.x;
+    bool active = own.valid[0] && !own.blocked[0];
+    V3 o[1] = {own.o[0]}, d[1] = {own.d[0]};
+    float limit = own.limit[0];
+    bool blocked = false;
+    bool staged_wave = __all(ray_is_tame(o[0], d[0]));
     unsigned long long wave_tests = 0;
-    bool done = shadow_wave_done<R>(s);
-    for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
+    uint32_t tile = 0;
+    for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS, ++tile) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
-        if (__syncthreads_and(done)) break;
+        if (tile % SHADOW_COMPACT_TILES == 0) {
+            // pack the open rays: results so far, then the open ones' numbers in order, then every lane takes its new ray
+            if (active && blocked) ray_blocked[mine] = 1u;
+            const bool open = active && !blocked;
+            const Mask open_mask = ballot(open);
+            if (lane == 0) wave_open[wave] = static_cast<uint32_t>(__popcll(open_mask));
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < BLOCK / 64; ++w) { const uint32_t c = wave_open[w]; before += w < wave ? c : 0u; total += c; }
+            if (total == 0) break;                                     // uniform over the workgroup
+            if (open) open_ids[before + static_cast<uint32_t>(__popcll(open_mask & ((1ull << lane) - 1ull)))] = mine;
+            __syncthreads();
+            // lanes past the open rays of a partly filled wave repeat that wave's first ray (their results are dropped), so
+            // that they do not disturb the wave's common decisions; waves without any ray skip the tests
+            const uint32_t wave_first = wave * 64u;
+            active = threadIdx.x < total;
+            const uint32_t take = active ? threadIdx.x : (wave_first < total ? wave_first : 0u);
+            mine = open_ids[take];
+            const float4 p0 = parked[0][mine], p1 = parked[1][mine];
+            o[0] = xyz(p0); d[0] = xyz(p1); limit = p0.w;
+            blocked = false;
+            staged_wave = __all(ray_is_tame(o[0], d[0]));
+        }
+        __syncthreads();
         stage_tile<4>(lds, sc.tri, first, count);
         __syncthreads();
-        if (!done) {
-            wave_tests += shadow_live_tests<R>(s, count);
-            brute_force_tile<R, STAGED, false>(lds, first, count, s.o, s.d, staged_wave, [&](int r, uint32_t, float t) __attribute__((always_inline)) {
-                s.blocked[r] |= t < s.limit[r];
+        const Mask testing = ballot(active && !blocked);
+        if (testing != 0) {
+            wave_tests += static_cast<unsigned long long>(count) * static_cast<uint32_t>(__popcll(testing));
+            brute_force_tile<1, STAGED, false>(lds, first, count, o, d, staged_wave, [&](int, uint32_t, float t) __attribute__((always_inline)) {
+                blocked |= t < limit;
             });
-            done = shadow_wave_done<R>(s);
         }
     }
-    store_shadow_result<R>(st, s, light_bit, stat_slot(st, ST_SHADOW_TESTS_TRI), wave_tests);
+    if (active && blocked) ray_blocked[mine] = 1u;
+    __syncthreads();
+    if (own.valid[0] && !own.blocked[0] && ray_blocked[threadIdx.x]) atomicOr(&st.blocked[own.slot[0]], light_bit);
+    if (lane == 0 && wave_tests) atomicAdd(stat_slot(st, ST_SHADOW_TESTS_TRI), wave_tests);
 }
 
 // Any-hit of every hit point toward light first_light + blockIdx.y over the primitives of kind PRIM:
@@ -2861,9 +2905,9 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                     const uint32_t n_pt = group - n_dir;
                     // brute-force shadow scan of one kind toward lights first.. (n of them)
                     auto brute_force = [&](int prim, uint32_t n, uint32_t first_light) {
-                        const dim3 grid(prim == 0 ? tri_scan_blocks() : scan_blocks(), n);
-                        if (prim == 0 && plain_test) hipLaunchKernelGGL((k_shadow_tri_brute<TRI_RAYS_PER_LANE, false>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
-                        else if (prim == 0) hipLaunchKernelGGL((k_shadow_tri_brute<TRI_RAYS_PER_LANE, true>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
+                        const dim3 grid(prim == 0 ? ray_blocks() : scan_blocks(), n);    // the triangle scan takes one ray per lane
+                        if (prim == 0 && plain_test) hipLaunchKernelGGL((k_shadow_tri_brute<false>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
+                        else if (prim == 0) hipLaunchKernelGGL((k_shadow_tri_brute<true>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                         else if (prim == 1) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                         else hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                     };
