@@ -278,6 +278,8 @@ def main():
             # the frame the ranks assembled in the last step against one rendered by this rank alone (outside the timed steps)
             alone = scene.render(cam, fi.params(max_bounce_count=depth, flags=flags))
             out["frame_identical_to_single_rank_render"] = bool((alone["rgb"].reshape(-1) == frame.cpu().numpy()).all())
+        if not args.brute_force:
+            out["output_ms"] = output_stage(api, scene, cam, prm, tiles[0], frame, fi, torch, world)
         if not args.no_brute_force_leg:
             out["roofline"] = brute_force_leg(abi, fi, cam, scene, depth, args, label)
         if world == 1 and not args.no_cpu_baseline:
@@ -322,6 +324,32 @@ def single_process_bench(args, api, abi, results_fd):
     scene.close()
     sys.stdout.flush()
     os.write(results_fd, (json.dumps(out) + "\n").encode())
+
+
+def output_stage(api, scene, cam, prm, tiles, frame, fi, torch, world):
+    """The stage after the path (Source/main.cpp:93): framebuffer to the host, PNG encoding and writing; alone, and behind the
+    next frame (rt_write_png_begin / rt_write_png_end while this rank traces its share again).  Rank 0, outside the timed steps."""
+    import tempfile
+    t0 = time.perf_counter()
+    host = frame.cpu().numpy().reshape(fi.height, fi.width, 3)
+    d2h = time.perf_counter() - t0
+    path = os.path.join(tempfile.gettempdir(), "rt_bench_frame_%d.png" % os.getpid())
+    t0 = time.perf_counter()
+    api.write_png(path, host)
+    png = time.perf_counter() - t0
+    size = os.path.getsize(path)
+    t0 = time.perf_counter()
+    scene.render_tiles_device(cam, prm, tiles.data_ptr(), want_stats=False)
+    alone = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    api.write_png_begin(path, host)
+    scene.render_tiles_device(cam, prm, tiles.data_ptr(), want_stats=False)
+    api.write_png_end()
+    both = time.perf_counter() - t0
+    os.remove(path)
+    return {"framebuffer_to_host": d2h * 1e3, "png_encode_and_write": png * 1e3, "png_bytes": size, "raw_bytes": host.size,
+            "frame_share_alone": alone * 1e3, "frame_share_with_png_in_background": both * 1e3,
+            "note": "PNG: Sub filter, zlib level 3 in up to 16 pieces on host threads; pixels identical to the framebuffer (tests/test_integration_binding.py)"}
 
 
 def brute_force_leg(abi, fi, cam, scene, depth, args, label):

@@ -242,8 +242,12 @@ void rt_camera_setup(const float camera11[11], rt_camera_desc* out);
 int rt_render_file_info(const rt_file_info* info, uint8_t* rgb_out, rt_stats* stats);
 
 /* Write an RGB8 image as PNG (stands where main.cpp:93 calls stbi_write_png;
- * pixel-identical, not byte-identical). */
+ * pixel-identical, not byte-identical): Sub filter, deflate on up to 16 host threads. */
 int rt_write_png(const char* filename, uint32_t width, uint32_t height, const uint8_t* rgb);
+/* The same behind the caller's back: begin copies the pixels and returns while a thread encodes and writes them, so that
+ * the next frame can be traced meanwhile; end waits for the file and returns the writer's status.  One image at a time. */
+int rt_write_png_begin(const char* filename, uint32_t width, uint32_t height, const uint8_t* rgb);
+int rt_write_png_end(void);
 
 /* ---- test hook -----------------------------------------------------------------
  * Evaluates ONE device routine of the render loop on n items, so that the GPU forms of the

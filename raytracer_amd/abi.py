@@ -136,6 +136,8 @@ PROTOTYPES = {
     "rt_camera_setup": (None, [C.POINTER(C.c_float * 11), C.POINTER(CameraDesc)]),
     "rt_render_file_info": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "rt_write_png": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "rt_write_png_begin": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "rt_write_png_end": (C.c_int, []),
     "rt_debug_eval": (C.c_int, [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 

@@ -200,6 +200,15 @@ def write_png(filename, rgb):
     _check(lib().rt_write_png(os.fsencode(filename), rgb.shape[1], rgb.shape[0], rgb.ctypes.data))
 
 
+def write_png_begin(filename, rgb):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    _check(lib().rt_write_png_begin(os.fsencode(filename), rgb.shape[1], rgb.shape[0], rgb.ctypes.data))
+
+
+def write_png_end():
+    _check(lib().rt_write_png_end())
+
+
 def debug_eval(op, a, b, out_per_item, n=None):
     """rt_debug_eval: one device routine on n items; a, b are float32 arrays laid out as include/rt_amd.h says."""
     a = np.ascontiguousarray(a, np.float32)

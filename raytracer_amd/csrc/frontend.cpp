@@ -5,6 +5,7 @@
 // the same transform-stack products and the same fused/unfused rounding the reference
 // gets from clang's -ffp-contract=on in Source/maths.cpp.  This file is compiled with
 // -ffp-contract=off; every fused multiply-add is an explicit fmaf().
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -12,7 +13,10 @@
 #include <fstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <zlib.h>
 
 #include "rt_internal.h"
 
@@ -416,27 +420,58 @@ void rt_camera_setup(const float c[11], rt_camera_desc* out) {
     std::memcpy(out, v, sizeof v);
 }
 
-// Stored (uncompressed) deflate blocks inside a zlib stream: valid PNG, no compression.
-int rt_write_png(const char* filename, uint32_t width, uint32_t height, const uint8_t* rgb) {
-    if (!filename || !rgb || !width || !height) return rt_fail(RT_ERR_ARGUMENT, "rt_write_png: bad argument");
-    std::vector<uint8_t> raw;
-    raw.reserve(static_cast<size_t>(height) * (static_cast<size_t>(width) * 3 + 1));
-    for (uint32_t y = 0; y < height; ++y) {
-        raw.push_back(0);  // filter type none
-        raw.insert(raw.end(), rgb + static_cast<size_t>(y) * width * 3, rgb + static_cast<size_t>(y + 1) * width * 3);
+// PNG of an RGB8 image (stands where Source/main.cpp:93 calls stbi_write_png: same pixels, not the same bytes).
+// Rows are filtered with the Sub filter and deflated by zlib in up to 16 pieces on threads of their own: every piece but
+// the last ends on a full flush, which leaves it byte aligned and independent of the others, so the pieces concatenate
+// into one valid deflate stream; the Adler-32 of the whole is combined from the pieces'.
+static int write_png_impl(const char* filename, uint32_t width, uint32_t height, const uint8_t* rgb) {
+    const size_t row = static_cast<size_t>(width) * 3;
+    const uint32_t n_pieces = std::max(1u, std::min({16u, std::thread::hardware_concurrency(), (height + 31) / 32}));
+    const uint32_t rows_per_piece = (height + n_pieces - 1) / n_pieces;
+    struct Piece { std::vector<uint8_t> out; uLong adler = 1; size_t raw_bytes = 0; int rc = Z_OK; };
+    std::vector<Piece> pieces(n_pieces);
+    auto work = [&](uint32_t p) {
+        Piece& piece = pieces[p];
+        const uint32_t y0 = p * rows_per_piece, y1 = std::min(height, y0 + rows_per_piece);
+        if (y0 >= y1) return;
+        std::vector<uint8_t> raw(static_cast<size_t>(y1 - y0) * (row + 1));
+        for (uint32_t y = y0; y < y1; ++y) {
+            uint8_t* dst = raw.data() + static_cast<size_t>(y - y0) * (row + 1);
+            const uint8_t* src = rgb + static_cast<size_t>(y) * row;
+            dst[0] = 1;                                         // filter type Sub: each byte minus the byte three to its left
+            for (size_t i = 0; i < row; ++i) dst[1 + i] = static_cast<uint8_t>(src[i] - (i >= 3 ? src[i - 3] : 0));
+        }
+        piece.raw_bytes = raw.size();
+        piece.adler = adler32(adler32(0L, Z_NULL, 0), raw.data(), static_cast<uInt>(raw.size()));
+        z_stream zs;
+        std::memset(&zs, 0, sizeof zs);
+        if ((piece.rc = deflateInit2(&zs, 3, Z_DEFLATED, -15, 8, Z_FILTERED)) != Z_OK) return;
+        piece.out.resize(deflateBound(&zs, static_cast<uLong>(raw.size())) + 64);
+        zs.next_in = raw.data(); zs.avail_in = static_cast<uInt>(raw.size());
+        zs.next_out = piece.out.data(); zs.avail_out = static_cast<uInt>(piece.out.size());
+        const bool last = y1 == height;
+        const int rc = deflate(&zs, last ? Z_FINISH : Z_FULL_FLUSH);
+        piece.rc = (last ? rc == Z_STREAM_END : rc == Z_OK) && zs.avail_in == 0 ? Z_OK : Z_BUF_ERROR;
+        piece.out.resize(piece.out.size() - zs.avail_out);
+        deflateEnd(&zs);
+    };
+    {
+        std::vector<std::thread> threads;
+        for (uint32_t p = 1; p < n_pieces; ++p) threads.emplace_back(work, p);
+        work(0);
+        for (std::thread& t : threads) t.join();
     }
-    std::vector<uint8_t> z = {0x78, 0x01};
-    uint32_t s1 = 1, s2 = 0;
-    for (size_t pos = 0; pos < raw.size();) {
-        const size_t n = raw.size() - pos < 65535 ? raw.size() - pos : 65535;
-        z.push_back(pos + n == raw.size() ? 1 : 0);
-        z.push_back(static_cast<uint8_t>(n & 0xFF)); z.push_back(static_cast<uint8_t>(n >> 8));
-        z.push_back(static_cast<uint8_t>(~n & 0xFF)); z.push_back(static_cast<uint8_t>((~n >> 8) & 0xFF));
-        z.insert(z.end(), raw.begin() + static_cast<long>(pos), raw.begin() + static_cast<long>(pos + n));
-        for (size_t i = pos; i < pos + n; ++i) { s1 = (s1 + raw[i]) % 65521; s2 = (s2 + s1) % 65521; }
-        pos += n;
+    std::vector<uint8_t> z = {0x78, 0x9C};
+    uLong adler = 1;
+    bool first = true;
+    for (const Piece& piece : pieces) {
+        if (piece.rc != Z_OK) return rt_fail(RT_ERR_IO, "rt_write_png: deflate failed");
+        if (piece.raw_bytes == 0) continue;
+        z.insert(z.end(), piece.out.begin(), piece.out.end());
+        adler = first ? piece.adler : adler32_combine(adler, piece.adler, static_cast<z_off_t>(piece.raw_bytes));
+        first = false;
     }
-    put_be32(z, (s2 << 16) | s1);
+    put_be32(z, static_cast<uint32_t>(adler));
     std::vector<uint8_t> png = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     std::vector<uint8_t> ihdr;
     put_be32(ihdr, width); put_be32(ihdr, height);
@@ -450,6 +485,49 @@ int rt_write_png(const char* filename, uint32_t width, uint32_t height, const ui
     const size_t written = std::fwrite(png.data(), 1, png.size(), fp);
     std::fclose(fp);
     return written == png.size() ? 0 : rt_fail(RT_ERR_IO, "rt_write_png: short write");
+}
+
+int rt_write_png(const char* filename, uint32_t width, uint32_t height, const uint8_t* rgb) {
+    if (!filename || !rgb || !width || !height) return rt_fail(RT_ERR_ARGUMENT, "rt_write_png: bad argument");
+    try {
+        return write_png_impl(filename, width, height, rgb);
+    } catch (const std::exception& e) {
+        return rt_fail(RT_ERR_IO, e.what());
+    }
+}
+
+// The same in the background: the pixels are copied, a thread encodes and writes them, and the caller goes on (to the next frame).
+namespace {
+struct PendingImage {
+    std::thread worker;
+    std::vector<uint8_t> pixels;
+    std::string filename, error;
+    int rc = 0;
+    bool busy = false;
+} g_pending_image;
+}
+int rt_write_png_begin(const char* filename, uint32_t width, uint32_t height, const uint8_t* rgb) {
+    if (!filename || !rgb || !width || !height) return rt_fail(RT_ERR_ARGUMENT, "rt_write_png_begin: bad argument");
+    if (g_pending_image.busy) return rt_fail(RT_ERR_ARGUMENT, "rt_write_png_begin: an image is still being written (rt_write_png_end)");
+    try {
+        g_pending_image.pixels.assign(rgb, rgb + static_cast<size_t>(width) * height * 3);
+        g_pending_image.filename = filename;
+        g_pending_image.busy = true;
+        g_pending_image.worker = std::thread([width, height] {
+            g_pending_image.rc = rt_write_png(g_pending_image.filename.c_str(), width, height, g_pending_image.pixels.data());
+            if (g_pending_image.rc) g_pending_image.error = rt_last_error();
+        });
+    } catch (const std::exception& e) {
+        g_pending_image.busy = false;
+        return rt_fail(RT_ERR_IO, e.what());
+    }
+    return 0;
+}
+int rt_write_png_end(void) {
+    if (!g_pending_image.busy) return 0;
+    g_pending_image.worker.join();
+    g_pending_image.busy = false;
+    return g_pending_image.rc ? rt_fail(g_pending_image.rc, g_pending_image.error.c_str()) : 0;
 }
 
 }  // extern "C"

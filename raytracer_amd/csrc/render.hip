@@ -1913,7 +1913,10 @@ DEV ShadowRay make_shadow_ray(const State& st, uint32_t slot, bool point, V3 lv)
 // packs its open rays into as few waves as they fill (ray data parked in LDS, ids compacted in order with ballots);
 // waves left without rays only take part in the staging and the barriers.  The result does not depend on which lane
 // tests a ray: "blocked" is an OR over the triangles.
-constexpr uint32_t SHADOW_COMPACT_TILES = 4;
+#ifndef RT_SHADOW_COMPACT_TILES
+#define RT_SHADOW_COMPACT_TILES 4
+#endif
+constexpr uint32_t SHADOW_COMPACT_TILES = RT_SHADOW_COMPACT_TILES;
 template <bool STAGED>
 __global__ void __launch_bounds__(BLOCK) k_shadow_tri_brute(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
     __shared__ float4 lds[TILE_PRIMS * 4];

@@ -1,26 +1,36 @@
-"""Time each rank's share of a frame on one GPU (tile_world = N, ranks in turn): what an N-GPU run can reach at best (GPU box)."""
+"""Time each rank's share of a frame on one GPU (tile_world = N, ranks in turn): the bound an N-GPU run of the tile split
+cannot beat, before any exchange.  Run on the GPU box:  python scripts/rank_times.py [synthetic|scene7_4k] > profiles/...txt"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from raytracer_amd import api, distributed
+from raytracer_amd import api, distributed, synth
 
 api.init(0)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-fi = api.FileInfo(os.path.join(root, "tests", "golden", "scenes", "scene7.test"))
-fi.set_size(3840, 2160)
-cam = fi.camera()
-scene = api.Scene(fi.scene_desc)
-for world in (1, 2, 4, 8):
-    prm0 = fi.params(tile_world=world)
-    stride = distributed.stride_tiles(prm0, world)
-    buf = torch.zeros(stride * 768, dtype=torch.uint8, device="cuda:0")
-    times = []
-    for rank in range(world):
-        prm = fi.params(tile_rank=rank, tile_world=world)
-        scene.render_tiles_device(cam, prm, buf.data_ptr(), want_stats=True)   # warm-up (allocations)
-        t0 = time.perf_counter()
-        st = scene.render_tiles_device(cam, prm, buf.data_ptr(), want_stats=True)
-        times.append((time.perf_counter() - t0) * 1e3)
-    print("world %d: per-rank ms min %.2f max %.2f  -> ideal speed-up %.2f of %d (device_ms last rank %.2f)" % (world, min(times), max(times), times_1 / max(times) if world > 1 else 1.0, world, st.device_ms) if world > 1 else "world 1: %.2f ms (device %.2f)" % (times[0], st.device_ms))
-    if world == 1:
-        times_1 = times[0]
+for workload in (sys.argv[1:] or ["synthetic", "scene7_4k"]):
+    if workload == "synthetic":
+        fi = api.FileInfo(synth.ensure_scene_file())
+    else:
+        fi = api.FileInfo(os.path.join(root, "tests", "golden", "scenes", "scene7.test"))
+        fi.set_size(3840, 2160)
+    cam = fi.camera()
+    scene = api.Scene(fi.scene_desc)
+    print("%s @ %dx%d, maxdepth %d: wall time of rt_render_tiles_device per rank share, best of 3" % (workload, fi.width, fi.height, fi.max_recursion_depth))
+    whole = None
+    for world in (1, 2, 4, 8):
+        stride = distributed.stride_tiles(fi.params(tile_world=world), world)
+        buf = torch.zeros(stride * 768, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        times = []
+        for rank in range(world):
+            prm = fi.params(tile_rank=rank, tile_world=world)
+            best = 1e9
+            for _ in range(4):      # the first call sizes the arenas
+                t0 = time.perf_counter()
+                scene.render_tiles_device(cam, prm, buf.data_ptr(), want_stats=False)
+                best = min(best, (time.perf_counter() - t0) * 1e3)
+            times.append(best)
+        if world == 1:
+            whole = times[0]
+        print("  %d ranks: share min %.2f ms, max %.2f ms -> at best %.2fx of %d (whole frame %.2f ms)" % (world, min(times), max(times), whole / max(times), world, whole))
+    scene.close()

@@ -91,6 +91,28 @@ def test_png_reader_round_trip(tmp_path):
     assert np.array_equal(read_png_rgb8(path), rgb)
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (1, 700), (33, 5), (480, 640), (301, 1023)])
+def test_png_writer_pieces_concatenate_to_one_valid_stream(tmp_path, shape):
+    """rt_write_png deflates the rows in pieces on several threads; an independent decoder (PIL) must read the pixels back.
+    Also the background form (rt_write_png_begin / rt_write_png_end)."""
+    from PIL import Image
+    from raytracer_amd import api
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+    rgb = np.stack([(xx // 3 + yy) % 256, (yy // 2) % 256, rng.integers(0, 256, shape)], axis=2).astype(np.uint8)
+    a, b = str(tmp_path / "a.png"), str(tmp_path / "b.png")
+    api.write_png(a, rgb)
+    api.write_png_begin(b, rgb)
+    rgb_after = rgb.copy()
+    rgb[:] = 0                      # the writer works on its own copy
+    api.write_png_end()
+    for path in (a, b):
+        assert np.array_equal(np.array(Image.open(path).convert("RGB")), rgb_after)
+    assert np.array_equal(read_png_rgb8(a), rgb_after)
+    with pytest.raises(api.RtError):
+        api.write_png(str(tmp_path / "no_such_dir" / "x.png"), rgb_after)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["scene1", "scene6"])
 def test_reference_front_end_plus_binding_renders_the_reference_image(gpu, name):
