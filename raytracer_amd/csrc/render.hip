@@ -449,19 +449,55 @@ DEV bool box_keeps_grown(const BoxRay& r, float4 lo, float4 hi, float grow) {
 // The CLUSTER = 16 children of a node in one 128-byte record (8 x uint4), which is what a lane that
 // walks the node fetches: w[0] = (base.xyz, scale.x), w[1] = (scale.y, scale.z, -, -) as float bits,
 // w[2..7] = byte u of each: lo.x, hi.x, lo.y, hi.y, lo.z, hi.z of child u in units of `scale` above
-// `base`.  A child's box as decoded here, fma(q, scale, base), contains its box record: the builder
-// (k_prep_packed_children) evaluates this very expression and moves q until it does.  A node with a
+// `base`.  A child's box, fma(q, scale, base) per coordinate, contains its box record: the builder
+// (k_prep_packed_children) evaluates this expression and moves q until it does.  A node with a
 // child that is not a finite box has base = NaN: every child decodes to NaN and keeps every ray.
 // Against 16 separate 32-byte records this is a quarter of the bytes and 8 loads instead of 32.
 DEV uint32_t dword_of(uint4 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
-DEV float packed_coord(uint4 bytes, int child, float scale, float base) {
-    return fma_(static_cast<float>((dword_of(bytes, child >> 2) >> (8 * (child & 3))) & 255u), scale, base);
+// The slab test of a ray against the 16 children of a packed node without decoding their boxes: with
+// A = scale * inv and B = (base - o) * inv per axis (once per node), the ray parameter of the plane at byte q is
+// t = q * A + B, one fused multiply-add per plane instead of a decode, a subtraction and a product.
+// Against box_keeps on the decoded box this evaluates t with an ABSOLUTE error: A and B are rounded (eps * 255 scale
+// |inv| and 2 eps |base - o| |inv|), and the box the bytes stand for in real arithmetic may lie inside the decoded one
+// by the rounding of the builder's check (eps (|base| + 255 scale)).  Their sum is below
+//   S = 2 eps |inv| (|base| + 2 |base - o| + 510 scale)     per axis,
+// twice what is needed, and each plane is moved outward by it: the low planes use B - S sign(inv), the high ones
+// B + S sign(inv) (the low plane is the near one where inv > 0), so that the slab interval only grows.  What is
+// left is relative (the final rounding, the approximate reciprocal: below 4 eps) and is covered by the factor on
+// `far`, as in box_keeps.  `grow` enlarges every box (sphere_growth).  A zero direction component gives infinities
+// and NaNs on that axis, which min / max drop: the axis is then not tested (box_keeps is exact there; this form is
+// merely conservative).  base = NaN (a node the builder gave up on) keeps every ray, as before.
+struct NodeRay { V3 a, b_lo, b_hi; float limit; };
+DEV NodeRay make_node_ray(uint4 w0, uint4 w1, V3 o, V3 inv, float limit, float grow) {
+    const V3 base{__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
+    const V3 sc{__uint_as_float(w0.w), __uint_as_float(w1.x), __uint_as_float(w1.y)};
+    constexpr float TWO_EPS = 2.0f * 5.9604644775390625e-8f;
+    NodeRay n;
+    n.limit = limit;
+    auto axis = [&](float base_q, float scale_q, float o_q, float inv_q, float& a, float& b_lo, float& b_hi) __attribute__((always_inline)) {
+        const float bo = base_q - o_q;
+        a = scale_q * inv_q;
+        const float b = bo * inv_q;
+        const float reach = fma_(2.0f, __builtin_fabsf(bo), fma_(510.0f, scale_q, __builtin_fabsf(base_q)));
+        const float slack = fma_(reach, TWO_EPS, grow) * __builtin_fabsf(inv_q);
+        const float signed_slack = __builtin_copysignf(slack, inv_q);
+        b_lo = b - signed_slack;
+        b_hi = b + signed_slack;
+    };
+    axis(base.x, sc.x, o.x, inv.x, n.a.x, n.b_lo.x, n.b_hi.x);
+    axis(base.y, sc.y, o.y, inv.y, n.a.y, n.b_lo.y, n.b_hi.y);
+    axis(base.z, sc.z, o.z, inv.z, n.a.z, n.b_lo.z, n.b_hi.z);
+    return n;
 }
-DEV void decode_child(const uint4 (&w)[8], int child, float4& lo, float4& hi) {
-    const float bx = __uint_as_float(w[0].x), by = __uint_as_float(w[0].y), bz = __uint_as_float(w[0].z);
-    const float sx = __uint_as_float(w[0].w), sy = __uint_as_float(w[1].x), sz = __uint_as_float(w[1].y);
-    lo = make_float4(packed_coord(w[2], child, sx, bx), packed_coord(w[4], child, sy, by), packed_coord(w[6], child, sz, bz), 0.0f);
-    hi = make_float4(packed_coord(w[3], child, sx, bx), packed_coord(w[5], child, sy, by), packed_coord(w[7], child, sz, bz), 0.0f);
+DEV float packed_byte(uint4 bytes, int child) { return static_cast<float>((dword_of(bytes, child >> 2) >> (8 * (child & 3))) & 255u); }
+DEV bool child_keeps(const NodeRay& n, const uint4 (&w)[8], int child) {
+    const float ax = fma_(packed_byte(w[2], child), n.a.x, n.b_lo.x), bx = fma_(packed_byte(w[3], child), n.a.x, n.b_hi.x);
+    const float ay = fma_(packed_byte(w[4], child), n.a.y, n.b_lo.y), by = fma_(packed_byte(w[5], child), n.a.y, n.b_hi.y);
+    const float az = fma_(packed_byte(w[6], child), n.a.z, n.b_lo.z), bz = fma_(packed_byte(w[7], child), n.a.z, n.b_hi.z);
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    const float far = __builtin_fminf(tmax, n.limit) * 1.000002f;
+    return !(tmax < 0.0f) && !(tmin > far);
 }
 
 // Sphere (centre, radius^2) around a box record, for the per-wave test (packet_sphere_keeps)
@@ -1492,20 +1528,17 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             const uint32_t e = q_in[active ? i0 + lane : 0u];
             const uint32_t first = (e & NODE_MASK) * CLUSTER;
             const PairRay pr = pair_ray(e >> 24);
-            const BoxRay ray{pr.o, pr.inv, FLT_MAX};
-            const float gr = pr.grow;
             const uint32_t last = n_child - 1u;
             uint4 w[8];
             const uint4* __restrict__ src = nodes + static_cast<size_t>(e & NODE_MASK) * 8;
 #pragma unroll
             for (int v = 0; v < 8; ++v) w[v] = src[v];
+            const NodeRay node_ray = make_node_ray(w[0], w[1], pr.o, pr.inv, FLT_MAX, GROWN ? pr.grow : 0.0f);
             uint32_t keep_bits = 0;
 #pragma unroll
             for (int u = 0; u < static_cast<int>(CLUSTER); ++u) {
-                float4 lo, hi;
-                decode_child(w, u, lo, hi);
                 // no short circuit: the test is cheaper than a branch around it
-                const bool hit = GROWN ? box_keeps_grown(ray, lo, hi, gr) : box_keeps(ray, lo, hi);
+                const bool hit = child_keeps(node_ray, w, u);
                 const bool keep = (active & (first + u <= last)) & (hit | keep_all);
                 keep_bits |= keep ? 1u << u : 0u;
             }
@@ -2133,13 +2166,12 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             const uint4* __restrict__ src = nodes + static_cast<size_t>(e & NODE_MASK) * 8;
 #pragma unroll
             for (int v = 0; v < 8; ++v) w[v] = src[v];
+            const NodeRay node_ray = make_node_ray(w[0], w[1], ray.o, ray.inv, ray.limit, 0.0f);
             uint32_t keep_bits = 0;
 #pragma unroll
             for (int u = 0; u < static_cast<int>(CLUSTER); ++u) {
-                float4 lo, hi;
-                decode_child(w, u, lo, hi);
                 // no short circuit: the test is cheaper than a branch around it
-                const bool hit = box_keeps(ray, lo, hi);
+                const bool hit = child_keeps(node_ray, w, u);
                 const bool keep = (active & (first + u <= last)) & (hit | keep_all);
                 keep_bits |= keep ? 1u << u : 0u;
             }

@@ -115,3 +115,27 @@ def test_directional_light_that_is_not_of_unit_length(gpu, factor, name):
     for f in ("closest_rays", "hits", "shadow_rays", "shadow_blocked"):
         assert getattr(a["stats"], f) == getattr(b["stats"], f), f
     assert a["stats"].shadow_blocked > 0
+
+
+def test_scene7_large_region_against_the_unmodified_reference(gpu):
+    """A quarter of scene7's frame (the region with the model in it) against the reference itself: image and primary ids.
+    The oracle, being scalar, is kept to a 32x16 crop above; the reference's AVX path on all host threads does 320x240 in seconds.
+    Also the plain form of the triangle test (RT_FLAG_PLAIN_TEST) on the same region in brute-force mode."""
+    if not checkers.have_ref():
+        pytest.skip("oracle/_ref/librt_ref.so was not built (needs the reference sources)")
+    from raytracer_amd import abi
+    fi = gpu.FileInfo(scene_path("scene7"))
+    cam = fi.camera()
+    rect = dict(rect_x0=160, rect_y0=120, rect_w=320, rect_h=240)
+    scene = gpu.Scene(fi.scene_desc)
+    g = scene.render(cam, fi.params(**rect), want_ids=True)
+    staged = scene.render(cam, fi.params(flags=abi.RT_FLAG_NO_FILTER, **rect), want_ids=True)
+    plain = scene.render(cam, fi.params(flags=abi.RT_FLAG_NO_FILTER | abi.RT_FLAG_PLAIN_TEST, **rect), want_ids=True)
+    scene.close()
+    r = checkers.cpu_render(checkers.load_ref(), "ref_", fi.scene_desc, cam, fi.params(**rect), want_ids=True)
+    assert (g["ids"] < 0xFFFFFFFE).mean() > 0.2                      # the model covers a good part of the region
+    for other in (g, staged, plain):
+        assert np.array_equal(other["ids"], r["ids"])
+        assert np.array_equal(other["rgb"], r["rgb"])
+    for f in ("closest_rays", "hits", "shadow_rays", "shadow_blocked"):
+        assert getattr(g["stats"], f) == getattr(staged["stats"], f) == getattr(plain["stats"], f), f
