@@ -27,7 +27,7 @@ def run(first, count, against_ref=False):
         rng = np.random.default_rng(seed)
         kw = dict(n_triangles=int(rng.choice([0, 100, 1500])), n_ellipsoids=int(rng.choice([0, 20, 300])), n_spheres=int(rng.choice([0, 9, 300])),
                   n_lights=int(rng.integers(1, 4)), width=int(rng.integers(24, 72)), height=int(rng.integers(16, 48)), maxdepth=int(rng.integers(1, 6)), seed=seed,
-                  extent=float(rng.choice([1.0, 10.0, 300.0])), edge=float(rng.choice([0.05, 0.3, 1.5])),
+                  extent=float(rng.choice([1.0, 10.0, 300.0, 3000.0, 30000.0])), edge=float(rng.choice([0.05, 0.3, 1.5])),
                   ell_scale=(float(rng.choice([0.01, 0.1, 0.3])), float(rng.choice([0.4, 1.2]))), sphere_radius=(float(rng.choice([0.01, 0.1, 0.3])), float(rng.choice([0.4, 1.5]))))
         kw["edge"] *= kw["extent"] / 10.0
         if kw["n_triangles"] + kw["n_ellipsoids"] + kw["n_spheres"] == 0:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random scenes (raytracer_amd/synth.py with random parameters): the default mode and the forced walks
-must give the bytes, ids and ray counters of the brute-force mode.  GPU box:  python scripts/stress_parity.py FIRST_SEED COUNT"""
+must give the bytes, ids and ray counters of the brute-force mode (staged triangle test), and so must brute force with the test as written.  GPU box:  python scripts/stress_parity.py FIRST_SEED COUNT"""
 import os
 import sys
 import tempfile
@@ -20,7 +20,7 @@ def run(first, count):
         rng = np.random.default_rng(seed)
         kw = dict(n_triangles=int(rng.choice([0, 200, 3000, 20000, 60000])), n_ellipsoids=int(rng.choice([0, 30, 800, 4000])),
                   n_spheres=int(rng.choice([0, 9, 700, 3000])), n_lights=int(rng.integers(1, 5)), width=int(rng.integers(40, 200)), height=int(rng.integers(30, 120)),
-                  maxdepth=int(rng.integers(1, 6)), seed=seed, extent=float(rng.choice([1.0, 10.0, 300.0])), edge=float(rng.choice([0.01, 0.15, 1.5])),
+                  maxdepth=int(rng.integers(1, 6)), seed=seed, extent=float(rng.choice([1.0, 10.0, 300.0, 3000.0, 30000.0])), edge=float(rng.choice([0.01, 0.15, 1.5])),
                   ell_scale=(float(rng.choice([0.002, 0.05, 0.3])), float(rng.choice([0.4, 1.2]))), sphere_radius=(float(rng.choice([0.002, 0.05, 0.3])), float(rng.choice([0.4, 1.5]))))
         kw["edge"] *= kw["extent"] / 10.0
         if kw["n_triangles"] + kw["n_ellipsoids"] + kw["n_spheres"] == 0:
@@ -29,7 +29,8 @@ def run(first, count):
         scene = api.Scene(fi.scene_desc)
         cam = fi.camera()
         ref = scene.render(cam, fi.params(flags=abi.RT_FLAG_NO_FILTER), want_ids=True)
-        for name, flags in (("default", 0), ("walk_all", abi.RT_FLAG_WALK_ALL), ("deep_walk", abi.RT_FLAG_WALK_ALL | abi.RT_FLAG_DEEP_WALK)):
+        for name, flags in (("default", 0), ("walk_all", abi.RT_FLAG_WALK_ALL), ("deep_walk", abi.RT_FLAG_WALK_ALL | abi.RT_FLAG_DEEP_WALK),
+                            ("brute force, test as written", abi.RT_FLAG_NO_FILTER | abi.RT_FLAG_PLAIN_TEST)):
             g = scene.render(cam, fi.params(flags=flags), want_ids=True)
             same = np.array_equal(g["ids"], ref["ids"]) and np.array_equal(g["rgb"], ref["rgb"]) and all(
                 getattr(g["stats"], f) == getattr(ref["stats"], f) for f in ("closest_rays", "hits", "shadow_rays", "shadow_blocked"))

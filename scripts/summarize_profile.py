@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 sqlite outputs of scripts/profile.sh into the text summaries kept under profiles/.
+"""Turns the rocprofv3 sqlite outputs of scripts/profile_r2.sh into the text summaries kept under profiles/.
 
     python scripts/summarize_profile.py gpurun_out/prof_<tag> profiles/<name> [profiles/traffic.json]
 """
