@@ -372,7 +372,7 @@ def brute_force_leg(abi, fi, cam, scene, depth, args, label):
 
     variant = "false" if args.plain_test else "true"
     closest = kernel("k_closest_tri_brute<1,%s>" % variant, float(st.closest_tests[0]), st.closest_kind_ms[0], st.closest_kind_launches[0])
-    shadow = kernel("k_shadow_tri_brute<1,%s>" % variant, float(st.shadow_tests[0]), st.shadow_kind_ms[0], st.shadow_kind_launches[0])
+    shadow = kernel("k_shadow_tri_brute<%s>" % variant, float(st.shadow_tests[0]), st.shadow_kind_ms[0], st.shadow_kind_launches[0])
     measured = profile_figures(label, args.plain_test)
     out = {"bound": "valu_fp32", "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s"}
     out.update(closest)

@@ -176,6 +176,12 @@ int rt_render(const rt_scene* scene, const rt_camera_desc* camera, const rt_rend
  * RCCL gather consumes device buffers, and by the benchmark. */
 int rt_render_tiles_device(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params,
                            void* tiles_dev, rt_stats* stats);
+/* Frames in flight: rt_render_tiles_device in two halves.  begin starts the frame and returns a ticket; end waits for it and
+ * returns its status and statistics.  Up to two frames may be in flight per GPU (each has its own streams and ray-state arena):
+ * the first launches of one frame then run beside the thin last launches of the other, which matters when a frame is short
+ * (one rank's share of a split frame).  tiles_dev must stay valid until end; the frames' results do not depend on each other. */
+int rt_render_tiles_begin(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params, void* tiles_dev, int* ticket);
+int rt_render_tiles_end(int ticket, rt_stats* stats);
 /* rt_render_tiles_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
  * harnesses that forbid it); it has no counterpart in the reference.  The call allocates, creates and frees nothing:
  * the per-sample state lives in a fixed device array of the library (about 37 MB per GPU, held until the process ends),

@@ -113,6 +113,8 @@ PROTOTYPES = {
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_render": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "rt_render_tiles_device": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]),
+    "rt_render_tiles_begin": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p, C.POINTER(C.c_int)]),
+    "rt_render_tiles_end": (C.c_int, [C.c_int, C.POINTER(Stats)]),
     "rt_render_tiles_noalloc": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p]),
     "rt_rank_tile_count": (C.c_uint32, [C.POINTER(RenderParams)]),
     "rt_total_tile_count": (C.c_uint32, [C.POINTER(RenderParams)]),

@@ -141,6 +141,20 @@ class Scene:
         return stats
 
 
+def render_tiles_begin(scene, camera, params, tiles_dev_ptr):
+    """rt_render_tiles_begin: starts a frame, returns its ticket."""
+    ticket = C.c_int(-1)
+    _check(lib().rt_render_tiles_begin(scene._h, C.byref(camera), C.byref(params), C.c_void_p(tiles_dev_ptr), C.byref(ticket)))
+    return ticket.value
+
+
+def render_tiles_end(ticket):
+    """rt_render_tiles_end: waits for the frame, returns its statistics."""
+    stats = abi.Stats()
+    _check(lib().rt_render_tiles_end(ticket, C.byref(stats)))
+    return stats
+
+
 def render_tiles_noalloc(scene, camera, params, tiles_dev_ptr):
     """rt_render_tiles_noalloc into caller-owned device memory (an integer address)."""
     _check(lib().rt_render_tiles_noalloc(scene._h, C.byref(camera), C.byref(params), C.c_void_p(tiles_dev_ptr)))

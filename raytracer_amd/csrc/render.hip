@@ -601,25 +601,33 @@ DEV bool packet_sphere_keeps(const Packet& p, float4 c) {
     return !(along < thr) || !(sin_psi < 1.0f) || !(p.cw > 0.0f);
 }
 
-// ray_tracing.cpp:169-206; the far root is replaced by the near one at :202 and that is kept
-DEV float hit_sphere(V3 o, V3 d, float4 s) {
+// ray_tracing.cpp:169-206; the far root is replaced by the near one at :202 and that is kept.
+// In two parts for the brute-force scans: a wave all of whose lanes have a negative discriminant skips the square root
+// (IEEE, about 15 issue slots) and the rest; sphere_roots on a negative discriminant gives FLT_MAX, as the whole does.
+struct SphereFront { float mid, disc; };
+DEV SphereFront sphere_front(V3 o, V3 d, float4 s) {
     const V3 oc = sub(xyz(s), o);
-    const float mid = vdot(oc, d);
+    SphereFront f;
+    f.mid = vdot(oc, d);
     const float oc2 = vdot(oc, oc);
-    const float mid2 = mid * mid;
+    const float mid2 = f.mid * f.mid;
     const float perp2 = oc2 - mid2;
     const float r2 = s.w * s.w;
-    const float disc = r2 - perp2;
-    const bool none = disc < 0.0f;
-    const float h = sqrt_(disc);
-    const float d0 = mid - h;
-    const float d1 = mid + h;
+    f.disc = r2 - perp2;
+    return f;
+}
+DEV float sphere_roots(const SphereFront& f) {
+    const bool none = f.disc < 0.0f;
+    const float h = sqrt_(f.disc);
+    const float d0 = f.mid - h;
+    const float d1 = f.mid + h;
     const bool inv0 = none | (d0 < TOL);
     const bool inv1 = none | (d1 < TOL);
     const float p0 = inv0 ? FLT_MAX : d0;
     const float p1 = inv1 ? FLT_MAX : d0;
     return p0 < p1 ? p0 : p1;
 }
+DEV float hit_sphere(V3 o, V3 d, float4 s) { return sphere_roots(sphere_front(o, d, s)); }
 
 // ray_tracing.cpp:229-263
 DEV float hit_unit_sphere(V3 o, V3 d) {
@@ -1721,12 +1729,16 @@ __global__ void __launch_bounds__(BLOCK) k_closest_sph(DevScene sc, State st, ui
         __syncthreads();
         stage_tile<1>(lds, sc.sph, first, count);
         __syncthreads();
-#pragma unroll 2
         for (uint32_t k = 0; k < count; ++k) {
             const float4 s = lds[k];
+            SphereFront front[R];
+            Mask missed = ~0ull;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { front[r] = sphere_front(o[r], d[r], s); missed &= ballot(front[r].disc < 0.0f); }
+            if (missed == ballot(true)) continue;      // no lane of the wave has a real root
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const float t = hit_sphere(o[r], d[r], s);
+                const float t = sphere_roots(front[r]);
                 if (t < best_t[r]) { best_t[r] = t; best_k[r] = first + k; }
             }
         }
@@ -2262,11 +2274,15 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_sph(DevScene sc, State st, uin
         __syncthreads();
         if (!done) {
             wave_tests += shadow_live_tests<R>(s, count);
-#pragma unroll 2
             for (uint32_t k = 0; k < count; ++k) {
                 const float4 sp = lds[k];
+                SphereFront front[R];
+                Mask missed = ~0ull;
 #pragma unroll
-                for (int r = 0; r < R; ++r) s.blocked[r] |= hit_sphere(s.o[r], s.d[r], sp) < s.limit[r];
+                for (int r = 0; r < R; ++r) { front[r] = sphere_front(s.o[r], s.d[r], sp); missed &= ballot(front[r].disc < 0.0f); }
+                if (missed == ballot(true)) continue;      // no lane of the wave has a real root
+#pragma unroll
+                for (int r = 0; r < R; ++r) s.blocked[r] |= sphere_roots(front[r]) < s.limit[r];
             }
             done = shadow_wave_done<R>(s);
         }
@@ -2490,16 +2506,30 @@ struct Lane {
     uint32_t* host_counts = nullptr;        // pinned copy of `counts`, filled word by word as the host asks (fetch_count)
     hipEvent_t count_ready = nullptr;       // the word last asked for has arrived
 };
+// What one frame in the making needs: lanes (streams + ray-state arenas), the events between them, work counters.
+// A device has FRAME_SLOTS of them, so that the first launches of frame k+1 can fill the chip while the thin last
+// launches of frame k drain (rt_render_tiles_begin / rt_render_tiles_end); the plain render calls use slot 0.
+constexpr int FRAME_SLOTS = 2;
+struct FrameSlot {
+    Lane lanes[MAX_LANES];
+    hipEvent_t lanes_fork = nullptr, lanes_join[MAX_LANES] = {}, lanes_started[MAX_LANES] = {};
+    unsigned long long* stats = nullptr;    // STAT_COPIES x ST_COUNT words
+    std::vector<hipEvent_t> events;         // timing events, reused from call to call
+    std::mutex guard;                       // one frame at a time in this slot
+    // a frame started with rt_render_tiles_begin: driven by a host thread of its own
+    std::thread worker;
+    bool busy = false;
+    int rc = 0;
+    std::string error;
+    rt_stats stats_out;
+};
 struct Library {
     bool ready = false;
     int device = -1;
-    Lane lanes[MAX_LANES];
-    hipStream_t stream = nullptr;           // = lanes[0].stream: uploads, scene preparation, assembly
-    hipEvent_t lanes_fork = nullptr, lanes_join[MAX_LANES] = {}, lanes_started[MAX_LANES] = {};
-    unsigned long long* stats = nullptr;    // STAT_COPIES x ST_COUNT words
+    FrameSlot slots[FRAME_SLOTS];
+    hipStream_t stream = nullptr;           // = slots[0].lanes[0].stream: uploads, scene preparation, assembly
     unsigned char* scratch = nullptr;       // device address of `scratch` on this device (hipGetSymbolAddress)
-    std::mutex guard;                       // one call at a time uses the lanes, the arenas and the counters
-    std::vector<hipEvent_t> events;
+    std::mutex guard;                       // scene creation, box rebuilds, assembly, the test hook: one at a time
     // multi-GPU (rt_comm_*, rt_init_devices): this device's rank in a communicator, a stream for the exchange, tile buffers
     void* comm = nullptr;                   // ncclComm_t
     int comm_rank = 0, comm_world = 1;
@@ -2654,7 +2684,7 @@ struct Timer {
     // families: 0 closest-hit scans of a bounce (all kinds), 1 shadow scans of a light group (all kinds),
     // 2 + kind: one kind's closest-hit scan, 5 + kind: one kind's shadow scan (kind: 0 triangles, 1 spheres, 2 ellipsoids)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans[8];
-    Library* owner = nullptr;    // whose pool of events is used
+    FrameSlot* owner = nullptr;  // whose pool of events is used
     size_t next_event = 0;
     std::mutex guard;   // the lanes of a frame are driven by a host thread each
     hipEvent_t take() {
@@ -2727,10 +2757,11 @@ void launch_shadow_scan(bool deep, dim3 grid, hipStream_t on, const DevScene& sc
 }
 
 int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_render_params* prm, uint8_t* tiles_dev,
-                uint32_t* ids_dev /* rect-shaped, nullable */, rt_stats* stats, bool no_alloc = false) {
+                uint32_t* ids_dev /* rect-shaped, nullable */, rt_stats* stats, bool no_alloc = false, int slot_index = 0) {
     Library& lib = current_device();
     if (!lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
-    std::lock_guard<std::mutex> one_at_a_time(lib.guard);
+    FrameSlot& slot = lib.slots[slot_index];
+    std::lock_guard<std::mutex> one_at_a_time(slot.guard);
     if (!scene || !cam || !prm) return rt_fail(RT_ERR_ARGUMENT, "null argument");
     if (prm->width == 0 || prm->height == 0) return rt_fail(RT_ERR_ARGUMENT, "image size is zero");
     if (prm->max_bounce_count < 0 || static_cast<uint32_t>(prm->max_bounce_count) > MAX_BOUNCES) return rt_fail(RT_ERR_LIMIT, "max_bounce_count out of range (0..62)");
@@ -2751,21 +2782,24 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     }
     const size_t chunk_samples = static_cast<size_t>(chunk_tiles) * SAMPLES_PER_TILE;
     const uint32_t n_lanes = std::min(MAX_LANES, ceil_div(my_tiles, chunk_tiles));
-    if (!no_alloc) for (uint32_t l = 0; l < n_lanes; ++l) if (int rc = ensure_state(lib.lanes[l], chunk_samples)) return rc;
-    unsigned long long* const stats_dev = no_alloc ? reinterpret_cast<unsigned long long*>(lib.scratch + NOALLOC_STATE_BYTES + NOALLOC_COUNTS_BYTES) : lib.stats;
-    auto counts_of = [&](uint32_t l) { return no_alloc ? reinterpret_cast<uint32_t*>(lib.scratch + NOALLOC_STATE_BYTES) : lib.lanes[l].counts; };
+    if (!no_alloc) for (uint32_t l = 0; l < n_lanes; ++l) if (int rc = ensure_state(slot.lanes[l], chunk_samples)) return rc;
+    unsigned long long* const stats_dev = no_alloc ? reinterpret_cast<unsigned long long*>(lib.scratch + NOALLOC_STATE_BYTES + NOALLOC_COUNTS_BYTES) : slot.stats;
+    auto counts_of = [&](uint32_t l) { return no_alloc ? reinterpret_cast<uint32_t*>(lib.scratch + NOALLOC_STATE_BYTES) : slot.lanes[l].counts; };
 
     while (scene && scene->device != lib.device) scene = scene->next;   // the replica on this device
     if (!scene) return rt_fail(RT_ERR_ARGUMENT, "the scene has no replica on this device");
     DevScene sc = scene->dev;
-    hipStream_t stream = lib.stream;
+    hipStream_t stream = slot.lanes[0].stream;
     {   // the box records must hold for the eye as an origin too
         float need = sc.origin_bound;
         for (int i = 0; i < 3; ++i) need = std::fmax(need, 1.001f * std::fabs(cam->eye[i]) + 1.0e-3f);
         if (!(need <= scene->box_bound)) {
             if (!std::isfinite(need)) return rt_fail(RT_ERR_ARGUMENT, "camera eye is not finite");
-            build_boxes(scene, need, stream);
-            HIP_TRY(hipGetLastError());
+            std::lock_guard<std::mutex> rebuild(lib.guard);
+            if (!(need <= scene->box_bound)) {      // (rt_render_tiles_begin has done this already, with no other frame in flight)
+                build_boxes(scene, need, stream);
+                HIP_TRY(hipGetLastError());
+            }
         }
         sc.box_bound = scene->box_bound;
     }
@@ -2782,11 +2816,11 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
 
     State lane_state[MAX_LANES];
     for (uint32_t l = 0; l < n_lanes; ++l)
-        lane_state[l] = make_state(no_alloc ? static_cast<void*>(lib.scratch) : lib.lanes[l].state_mem, counts_of(l), stats_dev, chunk_samples, ids_dev != nullptr);
+        lane_state[l] = make_state(no_alloc ? static_cast<void*>(lib.scratch) : slot.lanes[l].state_mem, counts_of(l), stats_dev, chunk_samples, ids_dev != nullptr);
     HIP_TRY(hipMemsetAsync(stats_dev, 0, STAT_COPIES * ST_COUNT * sizeof(unsigned long long), stream));
 
     Timer timer_storage;
-    timer_storage.owner = &lib;
+    timer_storage.owner = &slot;
     Timer* timer = stats ? &timer_storage : nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     if (timer) { ev_begin = timer->take(); ev_end = timer->take(); if (ev_begin) HIP_TRY(hipEventRecord(ev_begin, stream)); }
@@ -2799,8 +2833,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     const bool force_deep = (prm->flags & RT_FLAG_DEEP_WALK) != 0;
     const bool walk[3] = {filter && sc.th.n > below, filter && sc.eh.n > below, filter && sc.sh.n > below};
     if (n_lanes > 1) {   // the other lanes start when the box records and the cleared counters are ready
-        HIP_TRY(hipEventRecord(lib.lanes_fork, lib.lanes[0].stream));
-        for (uint32_t l = 1; l < n_lanes; ++l) HIP_TRY(hipStreamWaitEvent(lib.lanes[l].stream, lib.lanes_fork, 0));
+        HIP_TRY(hipEventRecord(slot.lanes_fork, slot.lanes[0].stream));
+        for (uint32_t l = 1; l < n_lanes; ++l) HIP_TRY(hipStreamWaitEvent(slot.lanes[l].stream, slot.lanes_fork, 0));
     }
     // One chunk; every launch of it goes to the streams of its lane.
     // The lanes start one after the other: lane l + 1 begins when lane l has generated its rays, so that
@@ -2808,11 +2842,11 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     // starting it after the first scans of lane l gains nothing).
     std::atomic<uint32_t> started_count{0};   // lanes that have recorded (or given up recording) their lanes_started event
     auto run_chunk = [&](uint32_t first, uint32_t chunk) -> int {
-        Lane& lane = lib.lanes[chunk % n_lanes];
+        Lane& lane = slot.lanes[chunk % n_lanes];
         const hipStream_t stream = lane.stream;       // everything of this chunk goes to its lane
         if (chunk > 0 && chunk < n_lanes) {
             while (started_count.load(std::memory_order_acquire) < chunk) std::this_thread::yield();   // the event must have been recorded
-            HIP_TRY(hipStreamWaitEvent(stream, lib.lanes_started[chunk - 1], 0));
+            HIP_TRY(hipStreamWaitEvent(stream, slot.lanes_started[chunk - 1], 0));
         }
         const State st = lane_state[chunk % n_lanes];
         const uint32_t n_tiles = (my_tiles - first < chunk_tiles) ? my_tiles - first : chunk_tiles;
@@ -2845,7 +2879,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         };
         if (int rc = fetch_count(0)) return rc;
         if (chunk + 1 < n_lanes) {
-            const hipError_t recorded = hipEventRecord(lib.lanes_started[chunk], stream);
+            const hipError_t recorded = hipEventRecord(slot.lanes_started[chunk], stream);
             started_count.store(chunk + 1, std::memory_order_release);   // whatever happened: the next lane's thread is waiting for this
             HIP_TRY(recorded);
         }
@@ -3008,8 +3042,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         return rt_fail(lane_rc[l], lane_error[l].c_str());
     }
     for (uint32_t l = 1; l < n_lanes; ++l) {
-        HIP_TRY(hipEventRecord(lib.lanes_join[l], lib.lanes[l].stream));
-        HIP_TRY(hipStreamWaitEvent(stream, lib.lanes_join[l], 0));
+        HIP_TRY(hipEventRecord(slot.lanes_join[l], slot.lanes[l].stream));
+        HIP_TRY(hipStreamWaitEvent(stream, slot.lanes_join[l], 0));
     }
     if (timer && ev_end) HIP_TRY(hipEventRecord(ev_end, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -3303,20 +3337,22 @@ static int init_device(int device) {
     Library& lib = g_devices[device];
     if (lib.ready) return 0;
     HIP_TRY(hipSetDevice(device));
-    for (Lane& lane : lib.lanes) {
-        HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&lane.side_stream, hipStreamNonBlocking));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&lane.counts), 64 * sizeof(uint32_t)));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&lane.host_counts), 64 * sizeof(uint32_t), hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&lane.count_ready, hipEventDisableTiming));
+    for (FrameSlot& slot : lib.slots) {
+        for (Lane& lane : slot.lanes) {
+            HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&lane.side_stream, hipStreamNonBlocking));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&lane.counts), 64 * sizeof(uint32_t)));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&lane.host_counts), 64 * sizeof(uint32_t), hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&lane.count_ready, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&slot.lanes_fork, hipEventDisableTiming));
+        for (hipEvent_t& e : slot.lanes_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t& e : slot.lanes_started) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&slot.stats), STAT_COPIES * ST_COUNT * sizeof(unsigned long long)));
     }
-    lib.stream = lib.lanes[0].stream;
-    HIP_TRY(hipEventCreateWithFlags(&lib.lanes_fork, hipEventDisableTiming));
-    for (hipEvent_t& e : lib.lanes_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (hipEvent_t& e : lib.lanes_started) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    lib.stream = lib.slots[0].lanes[0].stream;
     HIP_TRY(hipStreamCreateWithFlags(&lib.comm_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&lib.comm_ready, hipEventDisableTiming));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&lib.stats), STAT_COPIES * ST_COUNT * sizeof(unsigned long long)));
     // this device's copy of the scratch array of rt_render_tiles_noalloc: its address, once, with the device current
     HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&lib.scratch), HIP_SYMBOL(scratch)));
     if (!lib.scratch) return rt_fail(RT_ERR_DEVICE, "rt_init: the scratch array has no device address");
@@ -3513,6 +3549,60 @@ int rt_render_tiles_device(const rt_scene* scene, const rt_camera_desc* camera, 
 int rt_render_tiles_noalloc(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params, void* tiles_dev) {
     if (!tiles_dev) return rt_fail(RT_ERR_ARGUMENT, "rt_render_tiles_noalloc: null output");
     return guarded([&] { return render_impl(scene, camera, params, static_cast<uint8_t*>(tiles_dev), nullptr, nullptr, true); });
+}
+
+// Frames in flight.  A frame ends with thin launches (the late bounces, the last chunk's tail) that leave most of the chip
+// idle, and the shorter the frame - one rank's share of a split frame - the larger that part.  begin starts a frame on a free
+// slot and returns; a host thread of the library drives it (it has to wait for the ray counts that size the launches).  With two
+// slots the first launches of the next frame run beside the last ones of this frame.  end waits for a frame and returns its status.
+int rt_render_tiles_begin(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params, void* tiles_dev, int* ticket) {
+    Library& lib = current_device();
+    if (!lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    if (!scene || !camera || !params || !tiles_dev || !ticket) return rt_fail(RT_ERR_ARGUMENT, "rt_render_tiles_begin: null argument");
+    return guarded([&]() -> int {
+        int free_slot = -1;
+        for (int i = 0; i < FRAME_SLOTS; ++i) if (!lib.slots[i].busy) { free_slot = i; break; }
+        if (free_slot < 0) return rt_fail(RT_ERR_LIMIT, "rt_render_tiles_begin: two frames are in flight already (rt_render_tiles_end)");
+        {   // box records that do not cover this camera are rebuilt here, while no other frame reads them
+            const rt_scene* replica = scene;
+            while (replica && replica->device != lib.device) replica = replica->next;
+            if (!replica) return rt_fail(RT_ERR_ARGUMENT, "the scene has no replica on this device");
+            float need = replica->dev.origin_bound;
+            for (int i = 0; i < 3; ++i) need = std::fmax(need, 1.001f * std::fabs(camera->eye[i]) + 1.0e-3f);
+            if (!(need <= replica->box_bound)) {
+                if (!std::isfinite(need)) return rt_fail(RT_ERR_ARGUMENT, "camera eye is not finite");
+                for (FrameSlot& other : lib.slots) if (other.busy && other.worker.joinable()) other.worker.join();   // still busy: its ticket stays good until _end
+                std::lock_guard<std::mutex> rebuild(lib.guard);
+                build_boxes(replica, need, lib.stream);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(lib.stream));
+            }
+        }
+        FrameSlot& slot = lib.slots[free_slot];
+        slot.busy = true;
+        slot.rc = 0;
+        const rt_camera_desc cam_copy = *camera;
+        const rt_render_params prm_copy = *params;
+        slot.worker = std::thread([&lib, &slot, free_slot, scene, cam_copy, prm_copy, tiles_dev] {
+            DeviceBinding bound(lib);
+            slot.rc = bound.ok ? guarded([&] { return render_impl(scene, &cam_copy, &prm_copy, static_cast<uint8_t*>(tiles_dev), nullptr, &slot.stats_out, false, free_slot); })
+                               : rt_fail(RT_ERR_DEVICE, "rt_render_tiles_begin: hipSetDevice failed in the frame's thread");
+            if (slot.rc) slot.error = g_last_error;
+        });
+        *ticket = free_slot;
+        return 0;
+    });
+}
+
+int rt_render_tiles_end(int ticket, rt_stats* stats) {
+    Library& lib = current_device();
+    if (!lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    if (ticket < 0 || ticket >= FRAME_SLOTS || !lib.slots[ticket].busy) return rt_fail(RT_ERR_ARGUMENT, "rt_render_tiles_end: no frame in flight under this ticket");
+    FrameSlot& slot = lib.slots[ticket];
+    if (slot.worker.joinable()) slot.worker.join();
+    slot.busy = false;
+    if (stats) *stats = slot.stats_out;
+    return slot.rc ? rt_fail(slot.rc, slot.error.c_str()) : 0;
 }
 
 int rt_assemble_tiles_device(const void* gathered, uint32_t stride_tiles, const rt_render_params* params, void* rgb_dev) {

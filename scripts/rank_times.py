@@ -32,5 +32,20 @@ for workload in (sys.argv[1:] or ["synthetic", "scene7_4k"]):
             times.append(best)
         if world == 1:
             whole = times[0]
-        print("  %d ranks: share min %.2f ms, max %.2f ms -> at best %.2fx of %d (whole frame %.2f ms)" % (world, min(times), max(times), whole / max(times), world, whole))
+        # the slowest rank's share again, two frames in flight (rt_render_tiles_begin / _end): time per frame in the steady state
+        slow = max(range(world), key=lambda r: times[r])
+        prm = fi.params(tile_rank=slow, tile_world=world)
+        bufs = [buf, torch.zeros_like(buf)]
+        torch.cuda.synchronize()
+        frames = 12
+        ticket = api.render_tiles_begin(scene, cam, prm, bufs[0].data_ptr())
+        t0 = time.perf_counter()
+        for k in range(1, frames + 1):
+            nxt = api.render_tiles_begin(scene, cam, prm, bufs[k % 2].data_ptr())
+            api.render_tiles_end(ticket)
+            ticket = nxt
+        in_flight = (time.perf_counter() - t0) * 1e3 / frames
+        api.render_tiles_end(ticket)
+        print("  %d ranks: share min %.2f ms, max %.2f ms -> at best %.2fx of %d (whole frame %.2f ms); two frames in flight: %.2f ms per frame -> %.2fx"
+              % (world, min(times), max(times), whole / max(times), world, whole, in_flight, whole / in_flight))
     scene.close()

@@ -98,3 +98,55 @@ def test_single_process_multi_device_entry_point(gpu, through_rccl):
         env["RT_AMD_COMM_ALWAYS"] = "1"
     done = subprocess.run([sys.executable, "-c", MULTI_SCRIPT % {"root": ROOT, "scene": scene_path("scene6")}], env=env, capture_output=True, text=True, timeout=300)
     assert done.returncode == 0 and "MULTI_OK" in done.stdout, done.stdout[-2000:] + done.stderr[-2000:]
+
+
+def test_two_frames_in_flight_give_the_frames_of_one_at_a_time(gpu):
+    """rt_render_tiles_begin / _end: two frames traced side by side (different shares of a split frame, then the same camera from two
+    places, which rebuilds the box records for the farther one) == the same frames one after the other; a third begin is refused."""
+    import torch
+    fi = gpu.FileInfo(scene_path("scene7"))
+    cam = fi.camera()
+    scene = gpu.Scene(fi.scene_desc)
+    rect = dict(rect_x0=120, rect_y0=90, rect_w=400, rect_h=300)
+    shares = [fi.params(tile_rank=r, tile_world=3, **rect) for r in range(3)]
+    n = max(gpu.rank_tile_count(p) for p in shares) * 768
+    want = [torch.zeros(n, dtype=torch.uint8, device="cuda:0") for _ in shares]
+    got = [torch.full((n,), 5, dtype=torch.uint8, device="cuda:0") for _ in shares]
+    torch.cuda.synchronize()
+    stats = [scene.render_tiles_device(cam, p, w.data_ptr()) for p, w in zip(shares, want)]
+    t0 = gpu.render_tiles_begin(scene, cam, shares[0], got[0].data_ptr())
+    t1 = gpu.render_tiles_begin(scene, cam, shares[1], got[1].data_ptr())
+    assert {t0, t1} == {0, 1}
+    with pytest.raises(gpu.RtError, match="two frames are in flight"):
+        gpu.render_tiles_begin(scene, cam, shares[2], got[2].data_ptr())
+    s0 = gpu.render_tiles_end(t0)
+    t2 = gpu.render_tiles_begin(scene, cam, shares[2], got[2].data_ptr())       # the freed slot
+    s1 = gpu.render_tiles_end(t1)
+    s2 = gpu.render_tiles_end(t2)
+    with pytest.raises(gpu.RtError, match="no frame in flight"):
+        gpu.render_tiles_end(t2)
+    torch.cuda.synchronize()
+    for w, g, a, b in zip(want, got, stats, (s0, s1, s2)):
+        k = gpu.rank_tile_count(shares[0]) * 768
+        assert w.any() and torch.equal(w[:k - 768], g[:k - 768])
+        for f in ("closest_rays", "hits", "shadow_rays", "shadow_blocked"):
+            assert getattr(a, f) == getattr(b, f), f
+    # a camera far outside the bound the box records were built for, begun while another frame is in flight
+    far = fi.camera()
+    for q in range(3):
+        far.eye[q] = cam.eye[q] * 40.0
+    prm = fi.params(**rect)
+    m = gpu.rank_tile_count(prm) * 768
+    near_want, far_want, near_got, far_got = (torch.zeros(m, dtype=torch.uint8, device="cuda:0") for _ in range(4))
+    torch.cuda.synchronize()
+    scene.render_tiles_device(cam, prm, near_want.data_ptr())
+    scene.render_tiles_device(far, prm, far_want.data_ptr())
+    scene2 = gpu.Scene(fi.scene_desc)                                            # fresh box records
+    ta = gpu.render_tiles_begin(scene2, cam, prm, near_got.data_ptr())
+    tb = gpu.render_tiles_begin(scene2, far, prm, far_got.data_ptr())
+    gpu.render_tiles_end(ta)
+    gpu.render_tiles_end(tb)
+    torch.cuda.synchronize()
+    assert torch.equal(near_want, near_got) and torch.equal(far_want, far_got)
+    scene.close()
+    scene2.close()
