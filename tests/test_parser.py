@@ -144,22 +144,8 @@ def test_set_size_recomputes_fov_x():
 
 
 def test_png_writer_roundtrip(tmp_path):
-    import zlib
+    from test_integration_binding import read_png_rgb8     # checks the signature, every chunk's CRC and the header, undoes the row filters
     rgb = (np.arange(7 * 5 * 3) % 251).astype(np.uint8).reshape(5, 7, 3)
     path = str(tmp_path / "out.png")
     api.write_png(path, rgb)
-    raw = open(path, "rb").read()
-    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
-    pos, idat, ihdr = 8, b"", None
-    while pos < len(raw):
-        n = int.from_bytes(raw[pos:pos + 4], "big")
-        kind, data = raw[pos + 4:pos + 8], raw[pos + 8:pos + 8 + n]
-        assert zlib.crc32(kind + data) == int.from_bytes(raw[pos + 8 + n:pos + 12 + n], "big")
-        if kind == b"IHDR":
-            ihdr = data
-        if kind == b"IDAT":
-            idat += data
-        pos += 12 + n
-    assert ihdr == (7).to_bytes(4, "big") + (5).to_bytes(4, "big") + bytes([8, 2, 0, 0, 0])
-    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(5, 1 + 7 * 3)
-    assert not rows[:, 0].any() and np.array_equal(rows[:, 1:].reshape(5, 7, 3), rgb)
+    assert np.array_equal(read_png_rgb8(path), rgb)
