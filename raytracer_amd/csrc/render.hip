@@ -601,6 +601,17 @@ DEV bool packet_sphere_keeps(const Packet& p, float4 c) {
     return !(along < thr) || !(sin_psi < 1.0f) || !(p.cw > 0.0f);
 }
 
+// A lower bound of the distance from any origin of the wave to any point of the sphere c (centre, radius^2) around a
+// node's box; the roundings are covered as in packet_sphere_keeps.  NaN when anything is not finite (a comparison
+// `> far` is then false: the node is kept).
+DEV float packet_sphere_distance(const Packet& p, float4 c) {
+    const V3 v = sub(xyz(c), p.O);
+    const float len = __builtin_amdgcn_sqrtf(vdot(v, v));
+    const float slack = 4.8e-7f * ((fabsf(c.x) + fabsf(c.y)) + (fabsf(c.z) + p.o1));
+    const float reach = (__builtin_amdgcn_sqrtf(c.w) + p.rho) + slack;
+    return fma_(len, 0.99998f, -(reach * 1.00002f));
+}
+
 // ray_tracing.cpp:169-206; the far root is replaced by the near one at :202 and that is kept.
 // In two parts for the brute-force scans: a wave all of whose lanes have a negative discriminant skips the square root
 // (IEEE, about 15 issue slots) and the rest; sphere_roots on a negative discriminant gives FLT_MAX, as the whole does.
@@ -1257,6 +1268,20 @@ constexpr uint32_t QCAP = RT_QCAP, PUSH_MAX = 256;
 #ifndef RT_SCAN_ATTR
 #define RT_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(5)))
 #endif
+#ifndef RT_SHORTEN_RAYS
+#define RT_SHORTEN_RAYS 1
+#endif
+#ifndef RT_ORDER_PASSES
+#define RT_ORDER_PASSES 3
+#endif
+#ifndef RT_ORDER_NEAR
+#define RT_ORDER_NEAR 0.125f
+#endif
+#ifndef RT_ORDER_MID
+#define RT_ORDER_MID 0.5f
+#endif
+constexpr uint32_t ORDER_PASSES = RT_ORDER_PASSES;
+constexpr float ORDER_NEAR = RT_ORDER_NEAR, ORDER_MID = RT_ORDER_MID;   // class limits, as fractions of the range of distances of the nodes a wave can reach
 constexpr uint32_t NODE_MASK = 0xFFFFFFu;
 // For every set bit b < n_bits of a lane's `bits`, append base + b*step.  Entries of one bit are contiguous, in lane order.
 DEV void push_bits(uint32_t* q, uint32_t& count, uint32_t bits, uint32_t n_bits, uint32_t base, uint32_t step) {
@@ -1408,10 +1433,17 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     constexpr int N_QUEUES = LEVELS;
     static_assert(64 * R <= PUSH_MAX && 64 * R <= 256, "a queue entry has 8 bits for the ray, a push adds at most PUSH_MAX entries");
     const Hierarchy& h = PRIM == 0 ? sc.th : (PRIM == 1 ? sc.eh : sc.sh);
-    constexpr uint32_t WAVE_LDS = N_QUEUES * QCAP + 64 * R;   // per wave: one queue per level ((ray, top node), (ray, cluster), (ray, leaf), with LEVELS = 4 also (ray, super node)), slot table
-    __shared__ uint32_t lds_queue[(BLOCK / 64) * WAVE_LDS];
-    // the wave's rays, staged once for the lanes that walk their pairs: (o, growth) (d, -) (1/d, -) per ray
+    // A hit found shortens the ray for the rest of the walk: a node that begins beyond the closest hit so far holds nothing
+    // closer (and nothing as close: the box test's `limit` is exclusive of ties by its safety factor).  The distance found
+    // so far is kept per ray of the wave, in LDS, as the bits of a positive float (their order as integers is the order of the
+    // floats).  Not for spheres, whose accepted distances may be negative (pack_hit_signed).
+    constexpr bool SHORTENS = RT_SHORTEN_RAYS && PRIM != 2;
     constexpr bool STAGED = RT_STAGE_RAYS(R, LEVELS);
+    // per wave: one queue per level ((ray, top node), (ray, cluster), (ray, leaf), with LEVELS = 4 also (ray, super node)), slot table,
+    // closest distances (with staged rays they live in a spare word of the ray instead: the workgroup's LDS decides how many fit a CU)
+    constexpr uint32_t WAVE_LDS = N_QUEUES * QCAP + 64 * R + (SHORTENS && !STAGED ? 64 * R : 0);
+    __shared__ uint32_t lds_queue[(BLOCK / 64) * WAVE_LDS];
+    // the wave's rays, staged once for the lanes that walk their pairs: (o, growth) (d, closest distance so far) (1/d, -) per ray
     __shared__ float4 lds_rays[STAGED ? (BLOCK / 64) * 64 * R * 3 : 1];
     const uint32_t n_rays = st.counts[bounce];
     const uint32_t* __restrict__ list_in = st.list[bounce & 1u];
@@ -1428,19 +1460,25 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     uint32_t q0_count = 0, q1_count = 0, q2_count = 0, qs_count = 0, n_full = 0, n_queued = 0;
     unsigned long long n_pairs = 0;
     float4* const wave_rays_lds = lds_rays + (STAGED ? wave * (64 * R * 3) : 0);
+    // closest distance found so far for ray r*64 + lane (SHORTENS)
+    auto best_word = [&](uint32_t ray) __attribute__((always_inline)) {
+        return STAGED ? reinterpret_cast<uint32_t*>(wave_rays_lds + ray * 3 + 1) + 3 : wave_slots + 64 * R + ray;
+    };
+    auto best_of = [&](uint32_t ray) __attribute__((always_inline)) { return SHORTENS ? __uint_as_float(*best_word(ray)) : FLT_MAX; };
     // ray number `ray` of the wave (r*64 + lane of its owner) for the lane that handles one of its pairs
-    struct PairRay { V3 o, d, inv; float grow; };
+    struct PairRay { V3 o, d, inv; float grow, best; };
     auto pair_ray = [&](uint32_t ray) __attribute__((always_inline)) {
         PairRay p;
         if (STAGED) {
             const float4 a = wave_rays_lds[ray * 3], b = wave_rays_lds[ray * 3 + 1], c = wave_rays_lds[ray * 3 + 2];
-            p.o = xyz(a); p.d = xyz(b); p.inv = xyz(c); p.grow = a.w;
+            p.o = xyz(a); p.d = xyz(b); p.inv = xyz(c); p.grow = a.w; p.best = SHORTENS ? b.w : FLT_MAX;
         } else {
             const uint32_t s = wave_slots[ray];
             p.o = {st.ox[s], st.oy[s], st.oz[s]};
             p.d = {st.dx[s], st.dy[s], st.dz[s]};
             p.inv = make_box_ray(p.o, p.d, FLT_MAX).inv;
             p.grow = PRIM == 2 ? sphere_growth(p.d, sc.box_bound) : 0.0f;
+            p.best = best_of(ray);
         }
         return p;
     };
@@ -1449,6 +1487,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     uint32_t slot[R];
     bool valid[R];
     float grow[R];
+    float d_len[R];         // length of the direction, rounded up (0 for a lane without a ray): distance found so far = closest t * d_len
     BoxRay box_ray[R];
     Packet packet;
     bool unsafe = false;    // an origin outside the bound the box records were built for: keep everything
@@ -1468,9 +1507,12 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             if (STAGED) {
                 float4* const mine = wave_rays_lds + (r * 64 + lane) * 3;
                 mine[0] = make_float4(o[r].x, o[r].y, o[r].z, grow[r]);
-                mine[1] = make_float4(d[r].x, d[r].y, d[r].z, 0.0f);
+                mine[1] = make_float4(d[r].x, d[r].y, d[r].z, FLT_MAX);
                 mine[2] = make_float4(box_ray[r].inv.x, box_ray[r].inv.y, box_ray[r].inv.z, 0.0f);
+            } else if (SHORTENS) {
+                *best_word(r * 64 + lane) = __float_as_uint(FLT_MAX);
             }
+            d_len[r] = valid[r] ? __builtin_amdgcn_sqrtf(vdot(d[r], d[r])) * 1.00001f : 0.0f;
             d[r] = normalise(d[r]);   // for the bound of the wave: reflected directions drift off unit length
             wave_slots[r * 64 + lane] = slot[r];
         }
@@ -1498,7 +1540,10 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
                 const PairRay pr = pair_ray(e >> 24);
                 uint32_t k;
                 const float t = pretests_then_full(sc, load_tri_pair(sc, e & NODE_MASK), pr.o, pr.d, n_full, k);
-                if (t < FLT_MAX) atomicMin(&st.key[s], pack_hit(t, k));
+                if (t < FLT_MAX) {
+                    atomicMin(&st.key[s], pack_hit(t, k));
+                    if (SHORTENS) atomicMin(best_word(e >> 24), __float_as_uint(t));
+                }
             }
         } else if (PRIM == 1) {
             for (uint32_t i = lane; i < q2_count; i += 64) {
@@ -1509,7 +1554,10 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
                 const float4* __restrict__ rec = sc.ell + static_cast<size_t>(k) * 6;
                 const float t = hit_ellipsoid(pr.o, pr.d, rec[0], rec[1], rec[2], rec[3], rec[4], rec[5]);
                 n_full++;
-                if (t < FLT_MAX) atomicMin(&st.key_ell[s], pack_hit(t, k));
+                if (t < FLT_MAX) {
+                    atomicMin(&st.key_ell[s], pack_hit(t, k));
+                    if (SHORTENS) atomicMin(best_word(e >> 24), __float_as_uint(t));
+                }
             }
         } else {
             for (uint32_t i = lane; i < q2_count; i += 64) {
@@ -1541,7 +1589,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             const uint4* __restrict__ src = nodes + static_cast<size_t>(e & NODE_MASK) * 8;
 #pragma unroll
             for (int v = 0; v < 8; ++v) w[v] = src[v];
-            const NodeRay node_ray = make_node_ray(w[0], w[1], pr.o, pr.inv, FLT_MAX, GROWN ? pr.grow : 0.0f);
+            const NodeRay node_ray = make_node_ray(w[0], w[1], pr.o, pr.inv, pr.best, GROWN ? pr.grow : 0.0f);
             uint32_t keep_bits = 0;
 #pragma unroll
             for (int u = 0; u < static_cast<int>(CLUSTER); ++u) {
@@ -1572,31 +1620,97 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     uint32_t& first_count = LEVELS == 4 ? qs_count : q0_count;
     auto drain_first = [&]() __attribute__((always_inline)) { if constexpr (LEVELS == 4) drain_supers(); else drain0(); };
 
-    wave_sync();
-    for (uint32_t c0 = split.first_prim; c0 < split.end_prim; c0 += 64) {
-        const size_t mine_at = min(c0 + lane, split.end_prim - 1u);
-        const float4 mine_lo = first_box[mine_at * 2], mine_hi = first_box[mine_at * 2 + 1];
-        const bool reach = packet_sphere_keeps(packet, box_sphere(mine_lo, mine_hi));
-        unsigned long long mask = __ballot((reach || keep_all) && c0 + lane < split.end_prim);
-        while (mask) {
-            const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mask));
-            mask &= mask - 1ull;
-            const float4 lo = readlane4(mine_lo, bit), hi = readlane4(mine_hi, bit);
-            uint32_t keep_bits = 0;
-            n_pairs += wave_rays;   // the per-ray tests of this top node
+    // The nodes of the starting level are visited nearest first: in three classes of their distance from the wave's origins
+    // (relative to the range of distances of what the wave can reach), each class in index order, and the queues are drained
+    // after every class, so that what a class finds shortens the rays for the classes behind it.  Per wave, a node farther
+    // than every ray's closest hit so far is dropped by the lane that holds it, before any per-ray test.  The classes of up
+    // to 32 steps of 64 nodes are kept as 2-bit codes per lane (3 = the wave cannot reach the node); longer lists are walked
+    // in one pass.  A walk from the top nodes first tests the super nodes above them, one per lane: a step none of whose
+    // four super nodes the wave can reach is skipped without looking at its top nodes.
+    const uint32_t n_steps = (split.end_prim - split.first_prim + 63u) / 64u;
+    const bool ordered = SHORTENS && ORDER_PASSES > 1 && n_steps <= 32u;
+    unsigned long long codes = ~0ull;
+    if (ordered) {
+        unsigned long long group_reach[2] = {~0ull, ~0ull};   // LEVELS = 3: bit s = the wave may reach super node first_prim / 16 + s
+        float near_key = FLT_MAX, far_key = -FLT_MAX;          // range of distances of the nodes the wave can reach
+        auto widen = [&](bool reach, float key) __attribute__((always_inline)) {
+            near_key = reach ? fminf(near_key, key) : near_key;   // fminf / fmaxf drop a NaN key
+            far_key = reach ? fmaxf(far_key, key) : far_key;
+        };
+        if constexpr (LEVELS == 3) {
+            const uint32_t first_super = split.first_prim / CLUSTER, end_super = (split.end_prim + CLUSTER - 1u) / CLUSTER;
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                keep_bits |= ((GROWN ? box_keeps_grown(box_ray[r], lo, hi, grow[r]) : box_keeps(box_ray[r], lo, hi)) || keep_all) && valid[r] ? 1u << r : 0u;
-            if (__any(keep_bits != 0u)) {
-                if (first_count + PUSH_MAX > QCAP) drain_first();
-                push_bits(q_first, first_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
+            for (uint32_t half = 0; half < 2; ++half) {
+                const uint32_t super = first_super + half * 64u + lane;
+                const size_t at = min(super, h.n_supers - 1u);
+                const float4 sphere = box_sphere(h.super_box[at * 2], h.super_box[at * 2 + 1]);
+                const bool reach = super < end_super && (packet_sphere_keeps(packet, sphere) || keep_all);
+                group_reach[half] = __ballot(reach);
+                widen(reach, packet_sphere_distance(packet, sphere));
+            }
+        } else {
+            for (uint32_t c0 = split.first_prim; c0 < split.end_prim; c0 += 64) {
+                const size_t mine_at = min(c0 + lane, split.end_prim - 1u);
+                const float4 sphere = box_sphere(first_box[mine_at * 2], first_box[mine_at * 2 + 1]);
+                widen(c0 + lane < split.end_prim && (packet_sphere_keeps(packet, sphere) || keep_all), packet_sphere_distance(packet, sphere));
             }
         }
+        near_key = wave_min(near_key);
+        const float per_unit = __builtin_amdgcn_rcpf(wave_max(far_key) - near_key);
+        uint32_t step = 0;
+        for (uint32_t c0 = split.first_prim; c0 < split.end_prim; c0 += 64, ++step) {
+            if (LEVELS == 3 && ((group_reach[step >> 4] >> (4u * (step & 15u))) & 15ull) == 0ull) continue;
+            const size_t mine_at = min(c0 + lane, split.end_prim - 1u);
+            const float4 sphere = box_sphere(first_box[mine_at * 2], first_box[mine_at * 2 + 1]);
+            const bool reach = (packet_sphere_keeps(packet, sphere) || keep_all) && c0 + lane < split.end_prim;
+            const float rel = (packet_sphere_distance(packet, sphere) - near_key) * per_unit;
+            const uint32_t cls = rel <= ORDER_NEAR ? 0u : (rel <= ORDER_MID ? 1u : 2u);    // NaN: the last class
+            codes &= ~(3ull << (2u * step));
+            codes |= static_cast<unsigned long long>(reach ? cls : 3u) << (2u * step);
+        }
     }
-    drain_first();
-    if constexpr (LEVELS == 4) drain0();
-    drain1();
-    drain2();
+    wave_sync();
+#pragma nounroll
+    for (uint32_t pass = 0; pass < (ordered ? 3u : 1u); ++pass) {
+        uint32_t step = 0;
+        for (uint32_t c0 = split.first_prim; c0 < split.end_prim; c0 += 64, ++step) {
+            const bool in_pass = (static_cast<uint32_t>(codes >> (2u * step)) & 3u) == pass;
+            if (ordered && !__any(in_pass)) continue;
+            const size_t mine_at = min(c0 + lane, split.end_prim - 1u);
+            const float4 mine_lo = first_box[mine_at * 2], mine_hi = first_box[mine_at * 2 + 1];
+            const float4 sphere = box_sphere(mine_lo, mine_hi);
+            bool reach = ordered ? in_pass : (packet_sphere_keeps(packet, sphere) || keep_all) && c0 + lane < split.end_prim;
+            if (SHORTENS) {   // what the drains so far have found
+                float far = 0.0f;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    box_ray[r].limit = best_of(r * 64 + lane);
+                    far = fmaxf(far, box_ray[r].limit * d_len[r]);
+                }
+                far = wave_max(far);
+                reach = reach && (!(packet_sphere_distance(packet, sphere) > far) || keep_all);
+            }
+            unsigned long long mask = __ballot(reach);
+            while (mask) {
+                const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mask));
+                mask &= mask - 1ull;
+                const float4 lo = readlane4(mine_lo, bit), hi = readlane4(mine_hi, bit);
+                uint32_t keep_bits = 0;
+                n_pairs += wave_rays;   // the per-ray tests of this top node
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    keep_bits |= ((GROWN ? box_keeps_grown(box_ray[r], lo, hi, grow[r]) : box_keeps(box_ray[r], lo, hi)) || keep_all) && valid[r] ? 1u << r : 0u;
+                if (__any(keep_bits != 0u)) {
+                    if (first_count + PUSH_MAX > QCAP) drain_first();
+                    push_bits(q_first, first_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
+                }
+            }
+        }
+        drain_first();
+        if constexpr (LEVELS == 4) drain0();
+        drain1();
+        drain2();
+    }
     if (PRIM == 0) block_add_stat(stat_slot(st, ST_FULL_TESTS), n_full);
     if (lane == 0 && n_pairs) atomicAdd(stat_slot(st, ST_PAIR_PRETESTS), n_pairs);
     if (lane == 0 && n_queued) atomicAdd(stat_slot(st, ST_QUEUED), static_cast<unsigned long long>(n_queued));
@@ -1629,7 +1743,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest_packet(DevScene sc, State st,
     const uint32_t slot = list_in[valid ? i : split.ray_base];
     const V3 o{st.ox[slot], st.oy[slot], st.oz[slot]};
     const V3 d{st.dx[slot], st.dy[slot], st.dz[slot]};
-    const BoxRay ray = make_box_ray(o, d, FLT_MAX);
+    BoxRay ray = make_box_ray(o, d, FLT_MAX);     // its limit follows the closest hit found (not for spheres: their accepted distances may be negative)
     const float grow = PRIM == 2 ? sphere_growth(d, sc.box_bound) : 0.0f;
     const bool unsafe = !(fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))) <= sc.box_bound);
     Packet packet;
@@ -1691,7 +1805,10 @@ __global__ void __launch_bounds__(BLOCK) k_closest_packet(DevScene sc, State st,
                             t = hit_sphere(o, d, sc.sph[k]);
                             n_full++;
                         }
-                        if (t < FLT_MAX && (t < best_t || (t == best_t && k < best_k))) { best_t = t; best_k = k; }
+                        if (t < FLT_MAX && (t < best_t || (t == best_t && k < best_k))) {
+                            best_t = t; best_k = k;
+                            if (RT_SHORTEN_RAYS && PRIM != 2) ray.limit = t;
+                        }
                     }
                 }
             }
