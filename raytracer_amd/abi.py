@@ -82,6 +82,9 @@ class Stats(C.Structure):
         ("shadow_kind_ms", C.c_double * 3),
         ("closest_kind_launches", C.c_uint64 * 3),
         ("shadow_kind_launches", C.c_uint64 * 3),
+        ("walk_waves", C.c_uint64 * 2),
+        ("first_level_nodes", C.c_uint64 * 2),
+        ("walk_steps", C.c_uint64 * 2),
     ]
 
     def as_dict(self):

@@ -160,7 +160,8 @@ struct State {
 // one hot address per counter serialises the atomics of a whole launch (10 ns each).
 constexpr int STAT_COPIES = 64;
 enum { ST_SAMPLES, ST_CULLED, ST_CLOSEST_RAYS, ST_HITS, ST_SHADOW_RAYS, ST_SHADOW_BLOCKED,
-       ST_SHADOW_TESTS_TRI, ST_SHADOW_TESTS_SPH, ST_SHADOW_TESTS_ELL, ST_FULL_TESTS, ST_PAIR_PRETESTS, ST_PAIR_PRETESTS_SHADOW, ST_LIVE, ST_QUEUED, ST_QUEUED_SHADOW, ST_FLOP, ST_FLOP_SHADOW, ST_COUNT };
+       ST_SHADOW_TESTS_TRI, ST_SHADOW_TESTS_SPH, ST_SHADOW_TESTS_ELL, ST_FULL_TESTS, ST_PAIR_PRETESTS, ST_PAIR_PRETESTS_SHADOW, ST_LIVE, ST_QUEUED, ST_QUEUED_SHADOW, ST_FLOP, ST_FLOP_SHADOW,
+       ST_FIRST_NODES, ST_FIRST_NODES_SHADOW, ST_WALK_BATCHES, ST_WALK_BATCHES_SHADOW, ST_WALK_WAVES, ST_WALK_WAVES_SHADOW, ST_COUNT };
 
 struct V3 { float x, y, z; };
 
@@ -460,44 +461,65 @@ DEV uint32_t dword_of(uint4 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i
 // Against box_keeps on the decoded box this evaluates t with an ABSOLUTE error: A and B are rounded (eps * 255 scale
 // |inv| and 2 eps |base - o| |inv|), and the box the bytes stand for in real arithmetic may lie inside the decoded one
 // by the rounding of the builder's check (eps (|base| + 255 scale)).  Their sum is below
-//   S = 2 eps |inv| (|base| + 2 |base - o| + 510 scale)     per axis,
-// twice what is needed, and each plane is moved outward by it: the low planes use B - S sign(inv), the high ones
-// B + S sign(inv) (the low plane is the near one where inv > 0), so that the slab interval only grows.  What is
-// left is relative (the final rounding, the approximate reciprocal: below 4 eps) and is covered by the factor on
-// `far`, as in box_keeps.  `grow` enlarges every box (sphere_growth).  A zero direction component gives infinities
-// and NaNs on that axis, which min / max drop: the axis is then not tested (box_keeps is exact there; this form is
-// merely conservative).  base = NaN (a node the builder gave up on) keeps every ray, as before.
-struct NodeRay { V3 a, b_lo, b_hi; float limit; };
+//   S = 2 eps |inv| (|base| + 2 |base - o| + 510 scale)     per axis;
+// the slack used is 2 eps |inv| (|base| + 3 |base - o| + 765 scale), more than twice what is needed.  Each plane is
+// moved outward by it, so that the slab interval only grows.
+// The sign of inv says which plane of an axis the ray meets first: orient_node swaps the low and high bytes of the axes
+// where inv < 0 (once per node, instead of a minimum and a maximum per child and axis), after which the "near" planes are
+// t = q_near * A + (B - slack) and the "far" ones t = q_far * A + (B + slack).  What is left is relative (the final
+// rounding, the approximate reciprocal: below 4 eps) and is covered by the factor 1.000002 on the far side, as in
+// box_keeps; it is folded into the far planes' B (as an addition that bounds it from above) and into the limit.
+// `grow` enlarges every box (sphere_growth).  A zero direction component gives infinities and NaNs on that axis:
+// min3 / max3 drop the NaNs, and an infinity left over is the verdict box_keeps would reach (the origin outside the
+// slab) or keeps the ray.  base = NaN (a node the builder gave up on) keeps every ray.
+struct NodeRay { V3 a, b_near, b_far; float limit_far; };
 DEV NodeRay make_node_ray(uint4 w0, uint4 w1, V3 o, V3 inv, float limit, float grow) {
     const V3 base{__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
     const V3 sc{__uint_as_float(w0.w), __uint_as_float(w1.x), __uint_as_float(w1.y)};
-    constexpr float TWO_EPS = 2.0f * 5.9604644775390625e-8f;
+    constexpr float TWO_EPS = 2.0f * 5.9604644775390625e-8f, FAR = 1.000002f;
     NodeRay n;
-    n.limit = limit;
-    auto axis = [&](float base_q, float scale_q, float o_q, float inv_q, float& a, float& b_lo, float& b_hi) __attribute__((always_inline)) {
+    n.limit_far = limit * FAR;
+    auto axis = [&](float base_q, float scale_q, float o_q, float inv_q, float& a, float& b_near, float& b_far) __attribute__((always_inline)) {
         const float bo = base_q - o_q;
         a = scale_q * inv_q;
         const float b = bo * inv_q;
-        const float reach = fma_(2.0f, __builtin_fabsf(bo), fma_(510.0f, scale_q, __builtin_fabsf(base_q)));
+        const float reach = fma_(3.0f, __builtin_fabsf(bo), fma_(765.0f, scale_q, __builtin_fabsf(base_q)));
         const float slack = fma_(reach, TWO_EPS, grow) * __builtin_fabsf(inv_q);
-        const float signed_slack = __builtin_copysignf(slack, inv_q);
-        b_lo = b - signed_slack;
-        b_hi = b + signed_slack;
+        b_near = b - slack;
+        const float late = b + slack;
+        // (FAR - 1) times the largest |t| a far plane of this node can have, so that q * A + b_far >= FAR * (q * A + late) where that is positive
+        b_far = fma_(FAR - 1.0f, fma_(255.0f, __builtin_fabsf(a), __builtin_fabsf(late)), late);
     };
-    axis(base.x, sc.x, o.x, inv.x, n.a.x, n.b_lo.x, n.b_hi.x);
-    axis(base.y, sc.y, o.y, inv.y, n.a.y, n.b_lo.y, n.b_hi.y);
-    axis(base.z, sc.z, o.z, inv.z, n.a.z, n.b_lo.z, n.b_hi.z);
+    axis(base.x, sc.x, o.x, inv.x, n.a.x, n.b_near.x, n.b_far.x);
+    axis(base.y, sc.y, o.y, inv.y, n.a.y, n.b_near.y, n.b_far.y);
+    axis(base.z, sc.z, o.z, inv.z, n.a.z, n.b_near.z, n.b_far.z);
     return n;
 }
+// w[2], w[4], w[6] become the bytes of the planes the ray meets first on x, y, z and w[3], w[5], w[7] those it meets last
+DEV void orient_node(uint4 (&w)[8], V3 inv) {
+    auto swap_if = [](uint4& lo, uint4& hi, bool flip) __attribute__((always_inline)) {
+        const uint4 l = lo, h = hi;
+        lo = make_uint4(flip ? h.x : l.x, flip ? h.y : l.y, flip ? h.z : l.z, flip ? h.w : l.w);
+        hi = make_uint4(flip ? l.x : h.x, flip ? l.y : h.y, flip ? l.z : h.z, flip ? l.w : h.w);
+    };
+    swap_if(w[2], w[3], inv.x < 0.0f);
+    swap_if(w[4], w[5], inv.y < 0.0f);
+    swap_if(w[6], w[7], inv.z < 0.0f);
+}
 DEV float packed_byte(uint4 bytes, int child) { return static_cast<float>((dword_of(bytes, child >> 2) >> (8 * (child & 3))) & 255u); }
+// on a node that went through orient_node
 DEV bool child_keeps(const NodeRay& n, const uint4 (&w)[8], int child) {
-    const float ax = fma_(packed_byte(w[2], child), n.a.x, n.b_lo.x), bx = fma_(packed_byte(w[3], child), n.a.x, n.b_hi.x);
-    const float ay = fma_(packed_byte(w[4], child), n.a.y, n.b_lo.y), by = fma_(packed_byte(w[5], child), n.a.y, n.b_hi.y);
-    const float az = fma_(packed_byte(w[6], child), n.a.z, n.b_lo.z), bz = fma_(packed_byte(w[7], child), n.a.z, n.b_hi.z);
-    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
-    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-    const float far = __builtin_fminf(tmax, n.limit) * 1.000002f;
-    return !(tmax < 0.0f) && !(tmin > far);
+    const float nx = fma_(packed_byte(w[2], child), n.a.x, n.b_near.x), fx = fma_(packed_byte(w[3], child), n.a.x, n.b_far.x);
+    const float ny = fma_(packed_byte(w[4], child), n.a.y, n.b_near.y), fy = fma_(packed_byte(w[5], child), n.a.y, n.b_far.y);
+    const float nz = fma_(packed_byte(w[6], child), n.a.z, n.b_near.z), fz = fma_(packed_byte(w[7], child), n.a.z, n.b_far.z);
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
+    const float tmax = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+    return !(tmax < 0.0f) && !(tmin > __builtin_fminf(tmax, n.limit_far));
+}
+// bit u set: child first + u of the node exists (the last node of a level may be short)
+DEV uint32_t children_present(uint32_t first, uint32_t n_child) {
+    const uint32_t left = n_child - first;     // first < n_child for every queued node
+    return left >= CLUSTER ? 0xFFFFu : (1u << left) - 1u;
 }
 
 // Sphere (centre, radius^2) around a box record, for the per-wave test (packet_sphere_keeps)
@@ -1458,6 +1480,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     uint32_t* const qs = q2 + QCAP;                        // (ray, super node), LEVELS = 4 only
     uint32_t* const wave_slots = q0 + N_QUEUES * QCAP;     // slot of ray r*64 + lane
     uint32_t q0_count = 0, q1_count = 0, q2_count = 0, qs_count = 0, n_full = 0, n_queued = 0;
+    uint32_t n_first = 0, n_batches = 0;    // per wave: nodes of the starting level tested per ray, steps of 64 (ray, node) pairs walked
     unsigned long long n_pairs = 0;
     float4* const wave_rays_lds = lds_rays + (STAGED ? wave * (64 * R * 3) : 0);
     // closest distance found so far for ray r*64 + lane (SHORTENS)
@@ -1584,20 +1607,19 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             const uint32_t e = q_in[active ? i0 + lane : 0u];
             const uint32_t first = (e & NODE_MASK) * CLUSTER;
             const PairRay pr = pair_ray(e >> 24);
-            const uint32_t last = n_child - 1u;
             uint4 w[8];
             const uint4* __restrict__ src = nodes + static_cast<size_t>(e & NODE_MASK) * 8;
 #pragma unroll
             for (int v = 0; v < 8; ++v) w[v] = src[v];
             const NodeRay node_ray = make_node_ray(w[0], w[1], pr.o, pr.inv, pr.best, GROWN ? pr.grow : 0.0f);
+            orient_node(w, pr.inv);
             uint32_t keep_bits = 0;
 #pragma unroll
             for (int u = 0; u < static_cast<int>(CLUSTER); ++u) {
                 // no short circuit: the test is cheaper than a branch around it
-                const bool hit = child_keeps(node_ray, w, u);
-                const bool keep = (active & (first + u <= last)) & (hit | keep_all);
-                keep_bits |= keep ? 1u << u : 0u;
+                keep_bits |= (child_keeps(node_ray, w, u) | keep_all) ? 1u << u : 0u;
             }
+            keep_bits = active ? keep_bits & children_present(first, n_child) : 0u;
 #pragma nounroll
             for (uint32_t quarter = 0; quarter < CLUSTER / 4; ++quarter) {     // not unrolled: one copy of the code behind drain_out
                 const uint32_t bits = (keep_bits >> (4u * quarter)) & 15u;
@@ -1608,6 +1630,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             }
         }
         n_pairs += static_cast<unsigned long long>(in_count) * CLUSTER;
+        n_batches += (in_count + 63u) / 64u;
         wave_sync();
         in_count = 0;
     };
@@ -1697,6 +1720,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
                 const float4 lo = readlane4(mine_lo, bit), hi = readlane4(mine_hi, bit);
                 uint32_t keep_bits = 0;
                 n_pairs += wave_rays;   // the per-ray tests of this top node
+                ++n_first;
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     keep_bits |= ((GROWN ? box_keeps_grown(box_ray[r], lo, hi, grow[r]) : box_keeps(box_ray[r], lo, hi)) || keep_all) && valid[r] ? 1u << r : 0u;
@@ -1714,6 +1738,11 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
     if (PRIM == 0) block_add_stat(stat_slot(st, ST_FULL_TESTS), n_full);
     if (lane == 0 && n_pairs) atomicAdd(stat_slot(st, ST_PAIR_PRETESTS), n_pairs);
     if (lane == 0 && n_queued) atomicAdd(stat_slot(st, ST_QUEUED), static_cast<unsigned long long>(n_queued));
+    if (lane == 0) {
+        atomicAdd(stat_slot(st, ST_FIRST_NODES), static_cast<unsigned long long>(n_first));
+        atomicAdd(stat_slot(st, ST_WALK_BATCHES), static_cast<unsigned long long>(n_batches));
+        atomicAdd(stat_slot(st, ST_WALK_WAVES), 1ull);
+    }
     {   // FLOP executed in per-ray tests (n_full is per lane; the others are wave totals)
         constexpr unsigned long long CHILD = 24, LEAF = PRIM == 0 ? 40 : (PRIM == 1 ? 95 : 19), FULL = PRIM == 0 ? 54 : 0;
         block_add_stat(stat_slot(st, ST_FLOP), FULL * n_full + (lane == 0 ? CHILD * n_pairs + LEAF * n_queued : 0ull));
@@ -2221,6 +2250,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     uint32_t* const qs = q2 + QCAP;                        // (ray, super node), LEVELS = 4 only
     uint32_t* const wave_slots = q0 + N_QUEUES * QCAP;     // slot of ray r*64 + lane
     uint32_t q0_count = 0, q1_count = 0, q2_count = 0, qs_count = 0, n_full = 0, n_queued = 0;
+    uint32_t n_first = 0, n_batches = 0;    // per wave: nodes of the starting level tested per ray, steps of 64 (ray, node) pairs walked
     unsigned long long n_pairs = 0;
     // shadow ray number `ray` of the wave (r*64 + lane of its owner) for the lane that handles one of its pairs
     struct PairRay { ShadowRay s; BoxRay box; };
@@ -2290,20 +2320,19 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             const uint32_t first = (e & NODE_MASK) * CLUSTER;
             active = active && !ray_blocked(e >> 24);
             const BoxRay ray = pair_ray(e >> 24).box;
-            const uint32_t last = n_child - 1u;
             uint4 w[8];
             const uint4* __restrict__ src = nodes + static_cast<size_t>(e & NODE_MASK) * 8;
 #pragma unroll
             for (int v = 0; v < 8; ++v) w[v] = src[v];
             const NodeRay node_ray = make_node_ray(w[0], w[1], ray.o, ray.inv, ray.limit, 0.0f);
+            orient_node(w, ray.inv);
             uint32_t keep_bits = 0;
 #pragma unroll
             for (int u = 0; u < static_cast<int>(CLUSTER); ++u) {
                 // no short circuit: the test is cheaper than a branch around it
-                const bool hit = child_keeps(node_ray, w, u);
-                const bool keep = (active & (first + u <= last)) & (hit | keep_all);
-                keep_bits |= keep ? 1u << u : 0u;
+                keep_bits |= (child_keeps(node_ray, w, u) | keep_all) ? 1u << u : 0u;
             }
+            keep_bits = active ? keep_bits & children_present(first, n_child) : 0u;
 #pragma nounroll
             for (uint32_t quarter = 0; quarter < CLUSTER / 4; ++quarter) {     // not unrolled: one copy of the code behind drain_out
                 const uint32_t bits = (keep_bits >> (4u * quarter)) & 15u;
@@ -2314,6 +2343,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             }
         }
         n_pairs += static_cast<unsigned long long>(in_count) * CLUSTER;
+        n_batches += (in_count + 63u) / 64u;
         wave_sync();
         in_count = 0;
     };
@@ -2348,6 +2378,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
                 const float4 lo = readlane4(mine_lo, bit), hi = readlane4(mine_hi, bit);
                 uint32_t keep_bits = 0;
                 n_pairs += live;   // the per-ray tests of this top node
+                ++n_first;
 #pragma unroll
                 for (int r = 0; r < R; ++r) keep_bits |= (box_keeps(box_ray[r], lo, hi) || keep_all) && valid[r] && !blocked[r] ? 1u << r : 0u;
                 if (__any(keep_bits != 0u)) {
@@ -2366,6 +2397,11 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
     if (PRIM == 0) block_add_stat(stat_slot(st, ST_FULL_TESTS), n_full);
     if ((threadIdx.x & 63u) == 0 && n_pairs) atomicAdd(stat_slot(st, ST_PAIR_PRETESTS_SHADOW), n_pairs);
     if ((threadIdx.x & 63u) == 0 && n_queued) atomicAdd(stat_slot(st, ST_QUEUED_SHADOW), static_cast<unsigned long long>(n_queued));
+    if ((threadIdx.x & 63u) == 0) {
+        atomicAdd(stat_slot(st, ST_FIRST_NODES_SHADOW), static_cast<unsigned long long>(n_first));
+        atomicAdd(stat_slot(st, ST_WALK_BATCHES_SHADOW), static_cast<unsigned long long>(n_batches));
+        atomicAdd(stat_slot(st, ST_WALK_WAVES_SHADOW), 1ull);
+    }
     {   // FLOP executed in per-ray tests (n_full is per lane; the others are wave totals)
         constexpr unsigned long long CHILD = 24, LEAF = PRIM == 0 ? 40 : (PRIM == 1 ? 71 : 19), FULL = PRIM == 0 ? 54 : 0;
         block_add_stat(stat_slot(st, ST_FLOP_SHADOW), FULL * n_full + ((threadIdx.x & 63u) == 0 ? CHILD * n_pairs + LEAF * n_queued : 0ull));
@@ -3186,6 +3222,9 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         stats->shadow_tests[0] = h[ST_SHADOW_TESTS_TRI]; stats->shadow_tests[1] = h[ST_SHADOW_TESTS_SPH]; stats->shadow_tests[2] = h[ST_SHADOW_TESTS_ELL];
         stats->full_tests = h[ST_FULL_TESTS]; stats->pair_pretests[0] = h[ST_PAIR_PRETESTS]; stats->pair_pretests[1] = h[ST_PAIR_PRETESTS_SHADOW];
         stats->queued_pairs[0] = h[ST_QUEUED]; stats->queued_pairs[1] = h[ST_QUEUED_SHADOW];
+        stats->first_level_nodes[0] = h[ST_FIRST_NODES]; stats->first_level_nodes[1] = h[ST_FIRST_NODES_SHADOW];
+        stats->walk_steps[0] = h[ST_WALK_BATCHES]; stats->walk_steps[1] = h[ST_WALK_BATCHES_SHADOW];
+        stats->walk_waves[0] = h[ST_WALK_WAVES]; stats->walk_waves[1] = h[ST_WALK_WAVES_SHADOW];
         stats->executed_flop[0] = h[ST_FLOP]; stats->executed_flop[1] = h[ST_FLOP_SHADOW];
         float ms = 0.0f;
         if (ev_begin && ev_end && hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) stats->device_ms = ms;
