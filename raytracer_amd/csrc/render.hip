@@ -464,8 +464,8 @@ DEV uint32_t dword_of(uint4 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i
 //   S = 2 eps |inv| (|base| + 2 |base - o| + 510 scale)     per axis;
 // the slack used is 2 eps |inv| (|base| + 3 |base - o| + 765 scale), more than twice what is needed.  Each plane is
 // moved outward by it, so that the slab interval only grows.
-// The sign of inv says which plane of an axis the ray meets first: orient_node swaps the low and high bytes of the axes
-// where inv < 0 (once per node, instead of a minimum and a maximum per child and axis), after which the "near" planes are
+// The sign of inv says which plane of an axis the ray meets first: load_oriented_node fetches the low and high bytes of
+// the axes where inv < 0 the other way round (instead of a minimum and a maximum per child and axis), after which the "near" planes are
 // t = q_near * A + (B - slack) and the "far" ones t = q_far * A + (B + slack).  What is left is relative (the final
 // rounding, the approximate reciprocal: below 4 eps) and is covered by the factor 1.000002 on the far side, as in
 // box_keeps; it is folded into the far planes' B (as an addition that bounds it from above) and into the limit.
@@ -495,19 +495,33 @@ DEV NodeRay make_node_ray(uint4 w0, uint4 w1, V3 o, V3 inv, float limit, float g
     axis(base.z, sc.z, o.z, inv.z, n.a.z, n.b_near.z, n.b_far.z);
     return n;
 }
-// w[2], w[4], w[6] become the bytes of the planes the ray meets first on x, y, z and w[3], w[5], w[7] those it meets last
-DEV void orient_node(uint4 (&w)[8], V3 inv) {
-    auto swap_if = [](uint4& lo, uint4& hi, bool flip) __attribute__((always_inline)) {
-        const uint4 l = lo, h = hi;
-        lo = make_uint4(flip ? h.x : l.x, flip ? h.y : l.y, flip ? h.z : l.z, flip ? h.w : l.w);
-        hi = make_uint4(flip ? l.x : h.x, flip ? l.y : h.y, flip ? l.z : h.z, flip ? l.w : h.w);
-    };
-    swap_if(w[2], w[3], inv.x < 0.0f);
-    swap_if(w[4], w[5], inv.y < 0.0f);
-    swap_if(w[6], w[7], inv.z < 0.0f);
+// Loads a node for a ray with reciprocal direction inv: w[2], w[4], w[6] are the bytes of the planes the ray meets first on
+// x, y, z and w[3], w[5], w[7] those it meets last.  The record holds low then high per axis.  BY_ADDRESS: the lane picks
+// with the address it loads from (no registers beyond the node's: the walks from the top nodes have none to spare);
+// otherwise the words are exchanged after the load (faster where registers allow: 1 M-triangle scene 302 -> 299 ms).
+template <bool BY_ADDRESS>
+DEV void load_oriented_node(const uint4* __restrict__ src, V3 inv, uint4 (&w)[8]) {
+    const bool fx = inv.x < 0.0f, fy = inv.y < 0.0f, fz = inv.z < 0.0f;
+    if constexpr (BY_ADDRESS) {
+        w[0] = src[0]; w[1] = src[1];
+        w[2] = src[2u + fx]; w[3] = src[3u - fx];
+        w[4] = src[4u + fy]; w[5] = src[5u - fy];
+        w[6] = src[6u + fz]; w[7] = src[7u - fz];
+    } else {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) w[v] = src[v];
+        auto swap_if = [](uint4& lo, uint4& hi, bool flip) __attribute__((always_inline)) {
+            const uint4 l = lo, h = hi;
+            lo = make_uint4(flip ? h.x : l.x, flip ? h.y : l.y, flip ? h.z : l.z, flip ? h.w : l.w);
+            hi = make_uint4(flip ? l.x : h.x, flip ? l.y : h.y, flip ? l.z : h.z, flip ? l.w : h.w);
+        };
+        swap_if(w[2], w[3], fx);
+        swap_if(w[4], w[5], fy);
+        swap_if(w[6], w[7], fz);
+    }
 }
 DEV float packed_byte(uint4 bytes, int child) { return static_cast<float>((dword_of(bytes, child >> 2) >> (8 * (child & 3))) & 255u); }
-// on a node that went through orient_node
+// on a node loaded by load_oriented_node
 DEV bool child_keeps(const NodeRay& n, const uint4 (&w)[8], int child) {
     const float nx = fma_(packed_byte(w[2], child), n.a.x, n.b_near.x), fx = fma_(packed_byte(w[3], child), n.a.x, n.b_far.x);
     const float ny = fma_(packed_byte(w[4], child), n.a.y, n.b_near.y), fy = fma_(packed_byte(w[5], child), n.a.y, n.b_far.y);
@@ -1282,14 +1296,21 @@ DEV void wave_sync() {
 #endif
 constexpr uint32_t QCAP = RT_QCAP, PUSH_MAX = 256;
 #ifndef RT_STAGE_RAYS
-#define RT_STAGE_RAYS(R, LEVELS) ((LEVELS) == 3)
+#define RT_STAGE_RAYS(R, LEVELS) 1
 #endif
-// The walking scans ask for at least 5 waves per SIMD, i.e. at most 96 VGPRs: left alone the shadow scans
-// take 97 to 109, which the allocation granule of 8 turns into 4 waves (1 M-triangle scene: 423 -> 399 ms;
-// the LDS of a workgroup, 27 to 32 KB, allows 5 workgroups per CU as well).  Brute force is left alone.
+// The walks from the top nodes ask for at least 5 waves per SIMD, i.e. at most 96 VGPRs: left alone the shadow scans
+// take 97 to 109, which the allocation granule of 8 turns into 4 waves (the LDS of a workgroup, 32 KB, allows 5
+// workgroups per CU as well).  The walks from the super nodes have a fourth queue: 38 KB of LDS, 4 workgroups per CU,
+// so they may use the 128 VGPRs of 4 waves per SIMD.  (Their rays used to be re-derived from the ray state for every
+// (ray, node) pair, two rays per lane, to stay at 5 workgroups: staged in LDS at 4 is faster, 308 -> 298 ms on the
+// 1 M-triangle scene.)  Brute force is left alone.
 #ifndef RT_SCAN_ATTR
-#define RT_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(5)))
+#define RT_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(RT_STAGE_RAYS(R, LEVELS) && LEVELS == 4 ? (R == 1 ? 4 : 3) : 5)))
 #endif
+#ifndef RT_DEEP_RAYS
+#define RT_DEEP_RAYS 1
+#endif
+constexpr int DEEP_RAYS = RT_DEEP_RAYS;   // rays per lane of the walks that start at the super nodes
 #ifndef RT_SHORTEN_RAYS
 #define RT_SHORTEN_RAYS 1
 #endif
@@ -1608,11 +1629,8 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             const uint32_t first = (e & NODE_MASK) * CLUSTER;
             const PairRay pr = pair_ray(e >> 24);
             uint4 w[8];
-            const uint4* __restrict__ src = nodes + static_cast<size_t>(e & NODE_MASK) * 8;
-#pragma unroll
-            for (int v = 0; v < 8; ++v) w[v] = src[v];
+            load_oriented_node<LEVELS == 3>(nodes + static_cast<size_t>(e & NODE_MASK) * 8, pr.inv, w);
             const NodeRay node_ray = make_node_ray(w[0], w[1], pr.o, pr.inv, pr.best, GROWN ? pr.grow : 0.0f);
-            orient_node(w, pr.inv);
             uint32_t keep_bits = 0;
 #pragma unroll
             for (int u = 0; u < static_cast<int>(CLUSTER); ++u) {
@@ -2321,11 +2339,8 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             active = active && !ray_blocked(e >> 24);
             const BoxRay ray = pair_ray(e >> 24).box;
             uint4 w[8];
-            const uint4* __restrict__ src = nodes + static_cast<size_t>(e & NODE_MASK) * 8;
-#pragma unroll
-            for (int v = 0; v < 8; ++v) w[v] = src[v];
+            load_oriented_node<LEVELS == 3>(nodes + static_cast<size_t>(e & NODE_MASK) * 8, ray.inv, w);
             const NodeRay node_ray = make_node_ray(w[0], w[1], ray.o, ray.inv, ray.limit, 0.0f);
-            orient_node(w, ray.inv);
             uint32_t keep_bits = 0;
 #pragma unroll
             for (int u = 0; u < static_cast<int>(CLUSTER); ++u) {
@@ -2900,12 +2915,12 @@ const Hierarchy& hierarchy_of(const DevScene& sc, int prim) { return prim == 0 ?
 // starts at the super nodes; otherwise one ray per lane from the top nodes.
 template <int PRIM>
 void launch_closest_scan(bool deep, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b) {
-    if (deep) hipLaunchKernelGGL((k_closest_scan<2, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b);
+    if (deep) hipLaunchKernelGGL((k_closest_scan<DEEP_RAYS, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b);
     else hipLaunchKernelGGL((k_closest_scan<1, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b);
 }
 template <int PRIM>
 void launch_shadow_scan(bool deep, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b, uint32_t first_light, uint32_t group_first) {
-    if (deep) hipLaunchKernelGGL((k_shadow_scan<2, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first);
+    if (deep) hipLaunchKernelGGL((k_shadow_scan<DEEP_RAYS, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first);
     else hipLaunchKernelGGL((k_shadow_scan<1, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first);
 }
 
@@ -3065,7 +3080,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                     return;
                 }
                 const bool deep = force_deep || hierarchy_of(sc, prim).n_tops > TOPS_FOR_DEEP_WALK;
-                const dim3 grid(blocks_for(deep ? 2 : 1));
+                const dim3 grid(blocks_for(deep ? DEEP_RAYS : 1));
                 if (prim == 0) launch_closest_scan<0>(deep, grid, on, sc, sb, b);
                 else if (prim == 1) launch_closest_scan<1>(deep, grid, on, sc, sb, b);
                 else launch_closest_scan<2>(deep, grid, on, sc, sb, b);
@@ -3089,7 +3104,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         // box-hierarchy shadow scan of one kind toward the n lights first_light..
         auto shadow_scan = [&](const State& sb, int prim, uint32_t n, uint32_t b, uint32_t first_light, uint32_t group_first) {
             const bool deep = force_deep || hierarchy_of(sc, prim).n_tops > TOPS_FOR_DEEP_WALK;
-            const dim3 grid(blocks_for(deep ? 2 : 1), n);
+            const dim3 grid(blocks_for(deep ? DEEP_RAYS : 1), n);
             if (prim == 0) launch_shadow_scan<0>(deep, grid, stream, sc, sb, b, first_light, group_first);
             else if (prim == 1) launch_shadow_scan<1>(deep, grid, stream, sc, sb, b, first_light, group_first);
             else launch_shadow_scan<2>(deep, grid, stream, sc, sb, b, first_light, group_first);
