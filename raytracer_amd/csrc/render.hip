@@ -496,29 +496,15 @@ DEV NodeRay make_node_ray(uint4 w0, uint4 w1, V3 o, V3 inv, float limit, float g
     return n;
 }
 // Loads a node for a ray with reciprocal direction inv: w[2], w[4], w[6] are the bytes of the planes the ray meets first on
-// x, y, z and w[3], w[5], w[7] those it meets last.  The record holds low then high per axis.  BY_ADDRESS: the lane picks
-// with the address it loads from (no registers beyond the node's: the walks from the top nodes have none to spare);
-// otherwise the words are exchanged after the load (faster where registers allow: 1 M-triangle scene 302 -> 299 ms).
-template <bool BY_ADDRESS>
+// x, y, z and w[3], w[5], w[7] those it meets last.  The record holds low then high per axis, and the lane picks with the
+// address it loads from: no instruction and no register beyond the node's (exchanging the words after the load costs 24
+// conditional moves and, at 96 VGPRs, spills).
 DEV void load_oriented_node(const uint4* __restrict__ src, V3 inv, uint4 (&w)[8]) {
     const bool fx = inv.x < 0.0f, fy = inv.y < 0.0f, fz = inv.z < 0.0f;
-    if constexpr (BY_ADDRESS) {
-        w[0] = src[0]; w[1] = src[1];
-        w[2] = src[2u + fx]; w[3] = src[3u - fx];
-        w[4] = src[4u + fy]; w[5] = src[5u - fy];
-        w[6] = src[6u + fz]; w[7] = src[7u - fz];
-    } else {
-#pragma unroll
-        for (int v = 0; v < 8; ++v) w[v] = src[v];
-        auto swap_if = [](uint4& lo, uint4& hi, bool flip) __attribute__((always_inline)) {
-            const uint4 l = lo, h = hi;
-            lo = make_uint4(flip ? h.x : l.x, flip ? h.y : l.y, flip ? h.z : l.z, flip ? h.w : l.w);
-            hi = make_uint4(flip ? l.x : h.x, flip ? l.y : h.y, flip ? l.z : h.z, flip ? l.w : h.w);
-        };
-        swap_if(w[2], w[3], fx);
-        swap_if(w[4], w[5], fy);
-        swap_if(w[6], w[7], fz);
-    }
+    w[0] = src[0]; w[1] = src[1];
+    w[2] = src[2u + fx]; w[3] = src[3u - fx];
+    w[4] = src[4u + fy]; w[5] = src[5u - fy];
+    w[6] = src[6u + fz]; w[7] = src[7u - fz];
 }
 DEV float packed_byte(uint4 bytes, int child) { return static_cast<float>((dword_of(bytes, child >> 2) >> (8 * (child & 3))) & 255u); }
 // on a node loaded by load_oriented_node
@@ -1290,11 +1276,17 @@ DEV void wave_sync() {
 // Work queues of a wave, in LDS.  An entry is one word: (ray of the wave) << 24 | node, where
 // the ray is r*64 + lane of the lane that holds it (its slot is looked up in a per-wave table) and
 // the node is a top node, a cluster or a triangle position (hence at most 2^24 triangles).
-// A push adds up to 4 entries per lane.
+// A push adds up to PUSH_CHILDREN entries per lane.  256 entries per queue and two children per push keep the LDS of a
+// workgroup that walks from the super nodes (four queues, staged rays) at 31 KB: five workgroups per CU, like the walks
+// from the top nodes (384 entries, four children per push and four workgroups: 291 ms on the 1 M-triangle scene; this: 268 ms).
 #ifndef RT_QCAP
-#define RT_QCAP 384
+#define RT_QCAP 256
 #endif
-constexpr uint32_t QCAP = RT_QCAP, PUSH_MAX = 256;
+#ifndef RT_PUSH_CHILDREN
+#define RT_PUSH_CHILDREN 2
+#endif
+constexpr uint32_t PUSH_CHILDREN = RT_PUSH_CHILDREN;                  // children of a node handed down per push
+constexpr uint32_t QCAP = RT_QCAP, PUSH_MAX = 64 * PUSH_CHILDREN;   // the most entries a push can add
 // A walk step hands its kept children to the next queue, a quarter of the children at a time; that queue is worked off
 // first when it holds more than this (at most QCAP - PUSH_MAX, the room a push may need).  Early is better than full:
 // what the deeper levels find (a closer hit, a blocked ray) spares the pairs still queued above them, against lanes
@@ -1304,18 +1296,22 @@ constexpr uint32_t QCAP = RT_QCAP, PUSH_MAX = 256;
 #define RT_DRAIN_ABOVE 96
 #endif
 constexpr uint32_t DRAIN_ABOVE = RT_DRAIN_ABOVE;
+#ifndef RT_FIRST_DRAIN_ABOVE
+#define RT_FIRST_DRAIN_ABOVE (RT_QCAP < 384 ? RT_QCAP - 128 : 128)
+#endif
+constexpr uint32_t FIRST_DRAIN_ABOVE = RT_FIRST_DRAIN_ABOVE;   // the same for the queue of the level a walk starts at (a push adds at most 64 entries per ray of a lane)
+static_assert(FIRST_DRAIN_ABOVE + 128 <= QCAP, "a push must fit the queue");
 static_assert(DRAIN_ABOVE + PUSH_MAX <= QCAP, "a push must fit the queue");
 #ifndef RT_STAGE_RAYS
 #define RT_STAGE_RAYS(R, LEVELS) 1
 #endif
-// The walks from the top nodes ask for at least 5 waves per SIMD, i.e. at most 96 VGPRs: left alone the shadow scans
-// take 97 to 109, which the allocation granule of 8 turns into 4 waves (the LDS of a workgroup, 32 KB, allows 5
-// workgroups per CU as well).  The walks from the super nodes have a fourth queue: 38 KB of LDS, 4 workgroups per CU,
-// so they may use the 128 VGPRs of 4 waves per SIMD.  (Their rays used to be re-derived from the ray state for every
-// (ray, node) pair, two rays per lane, to stay at 5 workgroups: staged in LDS at 4 is faster, 308 -> 298 ms on the
-// 1 M-triangle scene.)  Brute force is left alone.
+// The walks ask for at least 5 waves per SIMD, i.e. at most 96 VGPRs: left alone the shadow scans take 97 to 109,
+// which the allocation granule of 8 turns into 4 waves; the LDS of a workgroup (26 to 31 KB) allows 5 workgroups per CU
+// as well.  The rays of a wave are staged in LDS once; walks from the super nodes used to re-derive a ray from the ray
+// state for every (ray, node) pair, two rays per lane, to save that LDS (308 -> 298 ms when it went, at 4 workgroups per
+// CU then).  Brute force is left alone.
 #ifndef RT_SCAN_ATTR
-#define RT_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(RT_STAGE_RAYS(R, LEVELS) && LEVELS == 4 ? (R == 1 ? 4 : 3) : 5)))
+#define RT_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(5)))
 #endif
 #ifndef RT_DEEP_RAYS
 #define RT_DEEP_RAYS 1
@@ -1484,7 +1480,7 @@ template <int R, int LEVELS, int PRIM>
 __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc, State st, uint32_t bounce) {
     static_assert(LEVELS == 3 || LEVELS == 4, "a walk from the top nodes or from the super nodes");
     constexpr int N_QUEUES = LEVELS;
-    static_assert(64 * R <= PUSH_MAX && 64 * R <= 256, "a queue entry has 8 bits for the ray, a push adds at most PUSH_MAX entries");
+    static_assert(64 * R <= 256, "a queue entry has 8 bits for the ray");
     const Hierarchy& h = PRIM == 0 ? sc.th : (PRIM == 1 ? sc.eh : sc.sh);
     // A hit found shortens the ray for the rest of the walk: a node that begins beyond the closest hit so far holds nothing
     // closer (and nothing as close: the box test's `limit` is exclusive of ties by its safety factor).  The distance found
@@ -1639,7 +1635,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             const uint32_t first = (e & NODE_MASK) * CLUSTER;
             const PairRay pr = pair_ray(e >> 24);
             uint4 w[8];
-            load_oriented_node<LEVELS == 3>(nodes + static_cast<size_t>(e & NODE_MASK) * 8, pr.inv, w);
+            load_oriented_node(nodes + static_cast<size_t>(e & NODE_MASK) * 8, pr.inv, w);
             const NodeRay node_ray = make_node_ray(w[0], w[1], pr.o, pr.inv, pr.best, GROWN ? pr.grow : 0.0f);
             uint32_t keep_bits = 0;
 #pragma unroll
@@ -1649,11 +1645,11 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
             }
             keep_bits = active ? keep_bits & children_present(first, n_child) : 0u;
 #pragma nounroll
-            for (uint32_t quarter = 0; quarter < CLUSTER / 4; ++quarter) {     // not unrolled: one copy of the code behind drain_out
-                const uint32_t bits = (keep_bits >> (4u * quarter)) & 15u;
+            for (uint32_t quarter = 0; quarter < CLUSTER / PUSH_CHILDREN; ++quarter) {     // not unrolled: one copy of the code behind drain_out
+                const uint32_t bits = (keep_bits >> (PUSH_CHILDREN * quarter)) & ((1u << PUSH_CHILDREN) - 1u);
                 if (__any(bits != 0u)) {
                     if (out_count > DRAIN_ABOVE) drain_out();
-                    push_bits(q_out, out_count, bits, 4u, (e & ~NODE_MASK) | (first + 4u * quarter), 1u);
+                    push_bits(q_out, out_count, bits, PUSH_CHILDREN, (e & ~NODE_MASK) | (first + PUSH_CHILDREN * quarter), 1u);
                 }
             }
         }
@@ -1753,7 +1749,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_closest_scan(DevScene sc
                 for (int r = 0; r < R; ++r)
                     keep_bits |= ((GROWN ? box_keeps_grown(box_ray[r], lo, hi, grow[r]) : box_keeps(box_ray[r], lo, hi)) || keep_all) && valid[r] ? 1u << r : 0u;
                 if (__any(keep_bits != 0u)) {
-                    if (first_count + PUSH_MAX > QCAP) drain_first();
+                    if (first_count > FIRST_DRAIN_ABOVE) drain_first();
                     push_bits(q_first, first_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
                 }
             }
@@ -2214,7 +2210,7 @@ template <int R, int LEVELS, int PRIM>
 __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
     static_assert(LEVELS == 3 || LEVELS == 4, "a walk from the top nodes or from the super nodes");
     constexpr int N_QUEUES = LEVELS;
-    static_assert(64 * R <= PUSH_MAX && 64 * R <= 256, "a queue entry has 8 bits for the ray, a push adds at most PUSH_MAX entries");
+    static_assert(64 * R <= 256, "a queue entry has 8 bits for the ray");
     const Hierarchy& h = PRIM == 0 ? sc.th : (PRIM == 1 ? sc.eh : sc.sh);
     constexpr uint32_t WAVE_LDS = N_QUEUES * QCAP + 64 * R;   // per wave: one queue per level ((ray, top node), (ray, cluster), (ray, leaf), with LEVELS = 4 also (ray, super node)), slot table
     __shared__ uint32_t lds_queue[(BLOCK / 64) * WAVE_LDS];
@@ -2349,7 +2345,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             active = active && !ray_blocked(e >> 24);
             const BoxRay ray = pair_ray(e >> 24).box;
             uint4 w[8];
-            load_oriented_node<LEVELS == 3>(nodes + static_cast<size_t>(e & NODE_MASK) * 8, ray.inv, w);
+            load_oriented_node(nodes + static_cast<size_t>(e & NODE_MASK) * 8, ray.inv, w);
             const NodeRay node_ray = make_node_ray(w[0], w[1], ray.o, ray.inv, ray.limit, 0.0f);
             uint32_t keep_bits = 0;
 #pragma unroll
@@ -2359,11 +2355,11 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
             }
             keep_bits = active ? keep_bits & children_present(first, n_child) : 0u;
 #pragma nounroll
-            for (uint32_t quarter = 0; quarter < CLUSTER / 4; ++quarter) {     // not unrolled: one copy of the code behind drain_out
-                const uint32_t bits = (keep_bits >> (4u * quarter)) & 15u;
+            for (uint32_t quarter = 0; quarter < CLUSTER / PUSH_CHILDREN; ++quarter) {     // not unrolled: one copy of the code behind drain_out
+                const uint32_t bits = (keep_bits >> (PUSH_CHILDREN * quarter)) & ((1u << PUSH_CHILDREN) - 1u);
                 if (__any(bits != 0u)) {
                     if (out_count > DRAIN_ABOVE) drain_out();
-                    push_bits(q_out, out_count, bits, 4u, (e & ~NODE_MASK) | (first + 4u * quarter), 1u);
+                    push_bits(q_out, out_count, bits, PUSH_CHILDREN, (e & ~NODE_MASK) | (first + PUSH_CHILDREN * quarter), 1u);
                 }
             }
         }
@@ -2407,7 +2403,7 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
 #pragma unroll
                 for (int r = 0; r < R; ++r) keep_bits |= (box_keeps(box_ray[r], lo, hi) || keep_all) && valid[r] && !blocked[r] ? 1u << r : 0u;
                 if (__any(keep_bits != 0u)) {
-                    if (first_count + PUSH_MAX > QCAP) drain_first();
+                    if (first_count > FIRST_DRAIN_ABOVE) drain_first();
                     push_bits(q_first, first_count, keep_bits, R, (lane << 24) | (c0 + bit), 64u << 24);
                 }
             }
