@@ -2444,6 +2444,8 @@ __global__ void __launch_bounds__(BLOCK) RT_SCAN_ATTR k_shadow_scan(DevScene sc,
 // part, whichever has more lanes waiting (leaves weighted by DFS_LEAF_WEIGHT: their part is cheaper).  Rays end at very
 // different times, so a wave owns 64 * rounds consecutive rays of the list and hands a new one to every idle lane
 // whenever DFS_REFILL_MIN lanes are idle: the wave stays full until its share runs out.
+// (The same walk for closest-hit rays loses: without an order among the children nothing shortens the ray early, 912 box
+// tests per ray against the 480 of the queued walk with its nearest-class-first order, 479 ms against 199.)
 #ifndef RT_DFS_LEAF_WEIGHT
 #define RT_DFS_LEAF_WEIGHT 3
 #endif
@@ -3075,22 +3077,24 @@ const Hierarchy& hierarchy_of(const DevScene& sc, int prim) { return prim == 0 ?
 // box-hierarchy scans of one kind, one or two rays per lane
 // box-hierarchy scans of one kind.  `deep` (more than TOPS_FOR_DEEP_WALK top nodes): two rays per lane and the walk
 // starts at the super nodes; otherwise one ray per lane from the top nodes.
-template <int PRIM>
-void launch_closest_scan(bool deep, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b) {
-    if (deep) hipLaunchKernelGGL((k_closest_scan<DEEP_RAYS, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b);
-    else hipLaunchKernelGGL((k_closest_scan<1, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b);
-}
 #ifndef RT_DFS_MAX_ROUNDS
 #define RT_DFS_MAX_ROUNDS 16
 #endif
 constexpr uint32_t DFS_MAX_ROUNDS = RT_DFS_MAX_ROUNDS, DFS_FILL_BLOCKS = 256 * 6 * 4;   // rays per lane over a wave's life, at most; workgroups below which a launch keeps one ray per lane
 template <int PRIM>
-void launch_shadow_scan(bool deep, dim3 grid, uint32_t ray_blocks, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b, uint32_t first_light, uint32_t group_first) {
+void launch_closest_scan(bool deep, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b) {
+    if (deep) hipLaunchKernelGGL((k_closest_scan<DEEP_RAYS, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b);
+    else hipLaunchKernelGGL((k_closest_scan<1, 3, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b);
+}
+template <int PRIM>
+void launch_shadow_scan(bool deep, bool depth_first, dim3 grid, uint32_t ray_blocks, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b, uint32_t first_light, uint32_t group_first) {
     // Large hierarchies: each lane walks the whole hierarchy for its ray, depth first; a wave takes 64 * rounds rays, and
     // there are enough workgroups to fill the chip several times over.  (1 M-triangle scene, 92 % of the shadow rays
     // blocked: 262 -> 199 ms per frame.  Small hierarchies keep the queued walk, whose first level is shared by the
     // wave: scene7, 19 % blocked, 16.9 ms against 17.6.)
-    if (RT_SHADOW_DFS && deep) {
+    // The other kinds of such a scene follow the triangles' scan and find most rays blocked already: walked depth first
+    // as well, their waves fill up with the rays that are still open (204 -> 199 ms).
+    if (RT_SHADOW_DFS && depth_first) {
         const uint32_t rounds = std::min(DFS_MAX_ROUNDS, std::max(1u, ray_blocks * grid.y / DFS_FILL_BLOCKS));
         hipLaunchKernelGGL(k_shadow_dfs<PRIM>, dim3(ceil_div(ray_blocks, rounds), grid.y), dim3(BLOCK), 0, on, sc, sb, b, first_light, group_first, rounds);
         return;
@@ -3279,10 +3283,11 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         // box-hierarchy shadow scan of one kind toward the n lights first_light..
         auto shadow_scan = [&](const State& sb, int prim, uint32_t n, uint32_t b, uint32_t first_light, uint32_t group_first) {
             const bool deep = force_deep || hierarchy_of(sc, prim).n_tops > TOPS_FOR_DEEP_WALK;
+            const bool depth_first = deep || (walk[0] && sc.th.n_tops > TOPS_FOR_DEEP_WALK);
             const dim3 grid(blocks_for(deep ? DEEP_RAYS : 1), n);
-            if (prim == 0) launch_shadow_scan<0>(deep, grid, ray_blocks(), stream, sc, sb, b, first_light, group_first);
-            else if (prim == 1) launch_shadow_scan<1>(deep, grid, ray_blocks(), stream, sc, sb, b, first_light, group_first);
-            else launch_shadow_scan<2>(deep, grid, ray_blocks(), stream, sc, sb, b, first_light, group_first);
+            if (prim == 0) launch_shadow_scan<0>(deep, depth_first, grid, ray_blocks(), stream, sc, sb, b, first_light, group_first);
+            else if (prim == 1) launch_shadow_scan<1>(deep, depth_first, grid, ray_blocks(), stream, sc, sb, b, first_light, group_first);
+            else launch_shadow_scan<2>(deep, depth_first, grid, ray_blocks(), stream, sc, sb, b, first_light, group_first);
         };
 
         // Per bounce: closest-hit scans -> k_hit (which also writes the reflected ray) -> list compaction ->
