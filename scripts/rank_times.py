@@ -48,4 +48,6 @@ for workload in (sys.argv[1:] or ["synthetic", "scene7_4k"]):
         api.render_tiles_end(ticket)
         print("  %d ranks: share min %.2f ms, max %.2f ms -> at best %.2fx of %d (whole frame %.2f ms); two frames in flight: %.2f ms per frame -> %.2fx"
               % (world, min(times), max(times), whole / max(times), world, whole, in_flight, whole / in_flight))
+        if world > 1:
+            print("      per rank: " + " ".join("%.2f" % t for t in times))
     scene.close()
