@@ -3078,9 +3078,14 @@ const Hierarchy& hierarchy_of(const DevScene& sc, int prim) { return prim == 0 ?
 // box-hierarchy scans of one kind.  `deep` (more than TOPS_FOR_DEEP_WALK top nodes): two rays per lane and the walk
 // starts at the super nodes; otherwise one ray per lane from the top nodes.
 #ifndef RT_DFS_MAX_ROUNDS
-#define RT_DFS_MAX_ROUNDS 16
+#define RT_DFS_MAX_ROUNDS 32
 #endif
-constexpr uint32_t DFS_MAX_ROUNDS = RT_DFS_MAX_ROUNDS, DFS_FILL_BLOCKS = 256 * 6 * 4;   // rays per lane over a wave's life, at most; workgroups below which a launch keeps one ray per lane
+#ifndef RT_DFS_FILL_BLOCKS
+#define RT_DFS_FILL_BLOCKS (256 * 6 * 4)
+#endif
+// rays per lane over a wave's life, at most (8: 208 ms, 16: 199 ms, 32: 195.5 ms on the 1 M-triangle scene); workgroups per round:
+// a launch of fewer keeps one ray per lane, so that it still fills the chip
+constexpr uint32_t DFS_MAX_ROUNDS = RT_DFS_MAX_ROUNDS, DFS_FILL_BLOCKS = RT_DFS_FILL_BLOCKS;
 template <int PRIM>
 void launch_closest_scan(bool deep, dim3 grid, hipStream_t on, const DevScene& sc, const State& sb, uint32_t b) {
     if (deep) hipLaunchKernelGGL((k_closest_scan<DEEP_RAYS, 4, PRIM>), grid, dim3(BLOCK), 0, on, sc, sb, b);
