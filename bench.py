@@ -28,8 +28,11 @@ sys.path.insert(0, ROOT)
 FLOP_TRI, FLOP_SPH, FLOP_ELL_CLOSEST, FLOP_ELL_SHADOW_POINT, FLOP_ELL_SHADOW_DIR = 54, 19, 95, 71, 62
 PEAK_FP32_TFLOPS = 157.3   # MI355X FP32 vector peak: 256 CU x 4 SIMD x 32 lanes x 2 FLOP x 2.4 GHz
 TILE_BYTES = 768
-# centred crops (WxH): the brute-force leg, and the CPU baseline (sized for 10-30 s of CPU work on 16 threads)
-BRUTE_CROP = {"synthetic": "512x288", "default": "512x288"}
+# centred crops (WxH): the brute-force leg, and the CPU baseline (sized for 10-30 s of CPU work on 16 threads).
+# The brute-force crop has to be large enough for its launches to fill the chip many times over, or the last workgroups
+# of a launch weigh on the figure: synthetic scene, closest-hit scan, 256x144: 0.387 of the peak, 512x288: 0.478,
+# 768x432: 0.493, 1024x576: 0.495 (33 s and 59 s of device time for the last two).
+BRUTE_CROP = {"synthetic": "768x432", "default": "1024x576"}
 CPU_CROP = {"synthetic": "48x27", "default": "240x135"}
 # how the generated scene departs from a plain reading of its specification (raytracer_amd/synth.py)
 SYNTHETIC_NOTES = ("seeded numpy PCG64 streams (triangles seed 1, ellipsoids 2, materials 3); light colour .15 and diffuse/specular U[0.1,0.5] "

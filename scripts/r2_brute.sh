@@ -3,7 +3,7 @@
 #   scripts/r2_brute.sh [workload] [crop WxH]
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-WL=${1:-scene7_4k}; CROP=${2:-512x288}
+WL=${1:-scene7_4k}; CROP=${2:-768x432}
 for mode in "" "--plain-test"; do
     timeout -k 10 400 python bench.py --workload $WL --brute-crop $CROP $mode --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/tmp_bf.log 2>gpurun_out/tmp_bf.err || { tail -5 gpurun_out/tmp_bf.err; exit 1; }
     python3 - "$mode" <<'PY'
