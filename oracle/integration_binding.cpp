@@ -1,10 +1,10 @@
 // TEST INFRASTRUCTURE ONLY - never linked into, imported by or called from the product path.
 //
-// The binding of INTEGRATION.md, section 1, compiled: the reference's own front end
+// The maintainer's binding, compiled: the reference's own front end
 // (parse_input_file, compiled from the unmodified sources where they lie, as in ref_harness.cpp)
 // feeding librt_amd.so through the two code blocks a maintainer adds to Source/main.cpp.
-// tests/test_integration_binding.py checks that the blocks here are the blocks of INTEGRATION.md
-// word for word, and (on a GPU box) that the image this flow renders is the reference's.
+// tests/test_integration_binding.py checks that the blocks here are the blocks of the integration guide at the
+// repository root word for word, and (on a GPU box) that the image this flow renders is the reference's.
 // Build: oracle/Makefile, target `binding` -> oracle/_ref/librt_binding.so (needs the reference sources).
 #include <cfloat>
 #include <cmath>

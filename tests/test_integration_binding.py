@@ -1,6 +1,7 @@
-"""The binding of INTEGRATION.md compiled and run, and the whole-flow entry points (Source/main.cpp:25-98 on the GPU path).
+"""The maintainer's binding (the code a maintainer adds to the reference's main.cpp, as the integration guide at the repository root
+shows it) compiled and run, and the whole-flow entry points (Source/main.cpp:25-98 on the GPU path).
 
-* CPU: the two code blocks of INTEGRATION.md section 1 are, word for word, the blocks compiled in oracle/integration_binding.cpp.
+* CPU: the two code blocks of the guide's first section are, word for word, the blocks compiled in oracle/integration_binding.cpp.
 * GPU: that translation unit (the reference's own parse_input_file + the binding + librt_amd.so) renders scene1 and scene6 to
   the reference's full-frame bytes (SHA-256 of the golden fixtures, generated from the unmodified reference);
   rt_render_file_info and the rt_amd_render command line program do the same, the latter through the PNG it writes.
@@ -29,14 +30,14 @@ def _words(text):
     return re.sub(r"\s+", " ", text).strip()
 
 
-def test_integration_md_blocks_are_the_compiled_ones():
+def test_the_guide_s_blocks_are_the_compiled_ones():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     blocks = re.findall(r"```cpp\n(.*?)```", doc, flags=re.S)
     assert len(blocks) >= 2
     src = open(os.path.join(ROOT, "oracle", "integration_binding.cpp")).read()
     for n in (1, 2):
         compiled = re.search(r"// \[binding block %d: begin\]\n(.*?)// \[binding block %d: end\]" % (n, n), src, flags=re.S).group(1)
-        assert _words(blocks[n - 1]) == _words(compiled), "block %d of INTEGRATION.md differs from oracle/integration_binding.cpp" % n
+        assert _words(blocks[n - 1]) == _words(compiled), "block %d of the integration guide differs from oracle/integration_binding.cpp" % n
 
 
 def read_png_rgb8(path):
