@@ -78,8 +78,9 @@ typedef struct rt_camera_desc {
 /* What to render.  width/height are the full image (they define the rays);
  * the rectangle [rect_x0, rect_x0+rect_w) x [rect_y0, rect_y0+rect_h) is the
  * part that is traced and returned (rect_w == 0 means the whole image).
- * The rectangle is cut into 16x16-pixel tiles in row-major order; the call
- * renders tiles t with  t % tile_world == tile_rank  (tile_world == 0 or 1:
+ * The rectangle is cut into 16x16-pixel tiles, tiles_x = ceil(rect_w / 16) per row.  Tile number t lies in row
+ * t / tiles_x at column (t % tiles_x - row) mod tiles_x: rows are rotated against each other, so that the tiles of one
+ * rank lie on diagonals.  The call renders tiles t with  t % tile_world == tile_rank  (tile_world == 0 or 1:
  * all of them).  This replaces the scanline queue of
  * Source/render_work_queue.cpp:59-80. */
 typedef struct rt_render_params {

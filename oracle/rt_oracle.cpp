@@ -487,7 +487,9 @@ int rto_render(const rt_scene_desc* desc, const rt_camera_desc* cam, const rt_re
             if (r >= rh) break;
             const unsigned y = y0 + r;
             for (unsigned xr = 0; xr < rw; ++xr) {
-                const uint32_t tile = (r / RT_TILE) * tiles_x + xr / RT_TILE;
+                // the tile numbering of the library (include/rt_amd.h): rows of tiles rotated against each other
+                const uint32_t tile_row = r / RT_TILE, place = (xr / RT_TILE + tile_row % tiles_x) % tiles_x;
+                const uint32_t tile = tile_row * tiles_x + place;
                 if (tile % tile_world != prm->tile_rank % tile_world) continue;
                 const unsigned x = x0 + xr;
                 float colour[3] = {0.0f, 0.0f, 0.0f};

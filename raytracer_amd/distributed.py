@@ -26,6 +26,12 @@ def tile_grid(params):
     return tiles_x, tiles_y, tiles_x * tiles_y
 
 
+def tile_position(t, tiles_x):
+    """(row, column) of tile number t: rows of tiles are rotated against each other (include/rt_amd.h)."""
+    row, place = divmod(t, tiles_x)
+    return row, (place - row) % tiles_x
+
+
 def rank_tiles(params, rank, world):
     """Global tile indices rank `rank` renders, in buffer order."""
     _, _, total = tile_grid(params)
@@ -44,7 +50,7 @@ def tile_buffer_from_image(rgb, params, rank, world):
     tiles_x, _, _ = tile_grid(params)
     out = np.zeros((stride_tiles(params, world), TILE, TILE, 3), np.uint8)
     for slot, t in enumerate(rank_tiles(params, rank, world)):
-        ty, tx = divmod(t, tiles_x)
+        ty, tx = tile_position(t, tiles_x)
         block = rgb[ty * TILE:min((ty + 1) * TILE, h), tx * TILE:min((tx + 1) * TILE, w)]
         out[slot, :block.shape[0], :block.shape[1]] = block
     return out
@@ -57,7 +63,7 @@ def assemble_tiles_host(gathered, params, world):
     img = np.zeros((h, w, 3), np.uint8)
     for t in range(total):
         rank, slot = t % world, t // world
-        ty, tx = divmod(t, tiles_x)
+        ty, tx = tile_position(t, tiles_x)
         hh, ww = min(TILE, h - ty * TILE), min(TILE, w - tx * TILE)
         img[ty * TILE:ty * TILE + hh, tx * TILE:tx * TILE + ww] = gathered[rank, slot, :hh, :ww]
     return img

@@ -27,7 +27,7 @@ def test_split_frames_assemble_to_the_single_rank_frame(gpu, world):
         mask = np.zeros(whole.shape[:2], bool)
         tiles_x = distributed.tile_grid(prm)[0]
         for t in distributed.rank_tiles(prm, rank, world):
-            ty, tx = divmod(t, tiles_x)
+            ty, tx = distributed.tile_position(t, tiles_x)
             mask[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = True
         assert np.array_equal(host[mask], whole[mask]) and not host[~mask].any()
     frame = torch.zeros(whole.size, dtype=torch.uint8, device="cuda:0")
