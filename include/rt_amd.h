@@ -140,10 +140,13 @@ typedef struct rt_stats {
     double   shadow_kind_ms[3];   /* the same for the shadow scans */
     uint64_t closest_kind_launches[3];
     uint64_t shadow_kind_launches[3];
-    uint64_t walk_waves[2];         /* hierarchy scans, closest-hit / shadow: wavefronts that walked (64 rays each, or 128 on large hierarchies) */
-    uint64_t first_level_nodes[2];  /* nodes of the level a walk starts at whose per-ray box tests ran, summed over those wavefronts */
+    uint64_t walk_waves[2];         /* hierarchy scans, closest-hit / shadow: wavefronts that walked (64 rays each; a wavefront of the depth-first
+                                       shadow walk of large hierarchies takes up to 2048 rays, 64 at a time) */
+    uint64_t first_level_nodes[2];  /* nodes of the level a walk starts at whose per-ray box tests ran, summed over those wavefronts
+                                       (the depth-first walk has no such level: it adds nothing here) */
     uint64_t walk_steps[2];         /* steps of up to 64 (ray, node) pairs, one pair per lane, below that level: 64 * walk_steps against the
-                                       pairs walked ((pair_pretests - per-ray tests of the first level) / 16) is the fill of the lanes */
+                                       pairs walked ((pair_pretests - per-ray tests of the first level) / 16) is the fill of the lanes; for the
+                                       depth-first walk a step serves either the lanes that hold a node or those that hold a leaf */
 } rt_stats;
 
 /* Thread safety: the library renders on one GPU per process with one set of streams and ray-state arenas; rt_scene_create,
