@@ -71,3 +71,17 @@ def test_tile_layout_helpers():
     img = np.random.default_rng(0).integers(0, 255, (37, 100, 3), dtype=np.uint8)
     gathered = np.stack([distributed.tile_buffer_from_image(img, p, r, 4) for r in range(4)])
     assert np.array_equal(distributed.assemble_tiles_host(gathered, p, 4), img)
+
+
+def test_tile_numbers_are_a_rotation_of_every_row():
+    """Tile number t sits in row t // tiles_x at column (t % tiles_x - row) mod tiles_x: every position once, and the
+    tiles of a rank on diagonals where the number of ranks divides the tiles per row."""
+    from raytracer_amd import abi, distributed
+    for w, h, world in ((3840, 2160, 8), (112, 48, 7), (100, 37, 3), (16, 16, 2), (640, 480, 4)):
+        p = abi.RenderParams(width=w, height=h)
+        tiles_x, tiles_y, total = distributed.tile_grid(p)
+        seen = {distributed.tile_position(t, tiles_x) for t in range(total)}
+        assert seen == {(r, c) for r in range(tiles_y) for c in range(tiles_x)}
+        if tiles_x % world == 0 and tiles_y > 1:
+            column_of_rank0 = [{c for (r, c) in (distributed.tile_position(t, tiles_x) for t in distributed.rank_tiles(p, 0, world)) if r == row} for row in (0, 1)]
+            assert column_of_rank0[0] != column_of_rank0[1]      # the next row is shifted: no columns of one rank
