@@ -102,8 +102,8 @@ typedef struct rt_render_params {
                                      library would scan them by brute force (same results; for tests and tuning) */
 #define RT_FLAG_PLAIN_TEST 8u     /* brute-force triangle scans evaluate the test exactly as written (three IEEE divisions per pair) instead of
                                      in stages that skip what the outcome does not depend on (same results; for measurements) */
-#define RT_FLAG_DEEP_WALK 4u      /* walk every hierarchy the way the library walks big ones (from the super nodes, two rays
-                                     per lane) whatever its size (same results; for tests and tuning) */
+#define RT_FLAG_DEEP_WALK 4u      /* walk every hierarchy the way the library walks big ones (closest-hit rays from the super
+                                     nodes, shadow rays depth first) whatever its size (same results; for tests and tuning) */
 
 /* Primary-hit id of one sample, as stored in the id buffer. */
 #define RT_ID_KIND_TRIANGLE  0u
