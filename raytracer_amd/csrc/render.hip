@@ -296,23 +296,35 @@ DEV float hit_triangle(V3 o, V3 d, float4 t0, float4 t1, float4 t2, float nn) {
 //              the tolerance is "parallel"; a lane whose two dot products differ in sign has a
 //              quotient t <= -0, which is "behind".  Either way the result is FLT_MAX.
 //   tri_head:  t by the IEEE division, the hit point, and alpha's numerator x1 = (ab x ap).n, all
-//              exactly as in hit_triangle.  alpha itself, RN(x1 / nn), is only ever compared:
-//              a1 = x1 * y with y = RN(1/nn) from the record is within 2^-22 (relative) of it, so
-//              a1 < -TINY implies alpha < 0, and a1 > 1 + BAND implies alpha > 1, which rejects
-//              the pair whatever beta is (beta < 0 rejects; beta >= 0 makes alpha + beta > 1).
-//   tri_tail:  beta's numerator and b1 = x2 * y likewise: b1 < -TINY implies beta < 0,
+//              exactly as in hit_triangle.  alpha itself, RN(x1 / nn), is only ever compared, and
+//              rounding is monotonic: with nn in [2^-60, 2^60], x1 < -2^-60 gives a quotient below
+//              -2^-120, which rounds to a negative normal number (alpha < 0), and x1 > x1_max, the
+//              record's RN(nn * (1 + 2^-20)) > nn * (1 + 2^-21), gives alpha > 1, which rejects the
+//              pair whatever beta is (beta < 0 rejects; beta >= 0 makes alpha + beta > 1).  Two
+//              comparisons of x1 itself: no multiplication, and t < tolerance is left to the tail
+//              (with the sign test of the front, or an eye in front of the scene, it is rare).
+//   tri_tail:  t >= tolerance; a1 = x1 * y with y = RN(1/nn) from the record is within 2^-22
+//              (relative) of alpha, so a1 < -TINY implies alpha < 0 and a1 > 1 + BAND alpha > 1;
+//              beta's numerator and b1 = x2 * y likewise: b1 < -TINY implies beta < 0,
 //              a1 + b1 > 1 + BAND implies alpha + beta > 1, and a1, b1 > TINY with
 //              a1 + b1 < 1 - BAND implies the pair is accepted with distance t.  Anything else
 //              (a quotient within TINY of zero, a sum within BAND of one) is "unsure": the caller
 //              then runs hit_triangle itself.
 // The argument needs every intermediate to be finite, so that no comparison meets a NaN that
-// hit_triangle would meet differently: the record holds y = NaN (every comparison false, hence
-// unsure) unless |a|, |a_to_b|, |a_to_c| <= TAME_COORD per component and nn is within
-// [2^-60, 2^60], and the scans take this path only for rays with |o| <= TAME_COORD and
-// |d| <= 2 per component (ray_is_tame).  Then for a lane that is not parallel |t| < 2^54,
+// hit_triangle would meet differently: the record holds y = x1_max = NaN unless |a|, |a_to_b|,
+// |a_to_c| <= TAME_COORD per component and nn is within [2^-60, 2^60] (a tile of the list that
+// holds such a record goes through hit_triangle: stage_tile), and the scans take this path only
+// for rays with |o| <= TAME_COORD and |d| <= 2 per component (ray_is_tame).  Then for a lane that is not parallel |t| < 2^54,
 // |ap| < 2^56 and both numerators stay below 2^96.
 constexpr float BARY_TINY = 1.0e-30f;
 constexpr float BARY_BAND = 9.5367431640625e-7f;   // 2^-20
+constexpr float X1_TINY = 8.673617379884035e-19f;  // 2^-60
+#ifndef RT_PREFETCH_RECORD
+#define RT_PREFETCH_RECORD 0
+#endif
+#ifndef RT_HEAD_T_TEST
+#define RT_HEAD_T_TEST 0
+#endif
 constexpr float TAME_COORD = 4096.0f;
 DEV bool ray_is_tame(V3 o, V3 d) {
     return fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))) <= TAME_COORD && fmaxf(fabsf(d.x), fmaxf(fabsf(d.y), fabsf(d.z))) <= 2.0f;
@@ -356,24 +368,28 @@ DEV float divide_in_range(float num, float den) {
     const float r1 = fma_(-den, q1, num);
     return fma_(r1, y1, q1);
 }
-struct TriHead { float t, a1; V3 ap; };
-DEV TriHead tri_head(V3 o, V3 d, const TriFront& f, float4 t0, float4 t1, float4 t2, float y, Mask& out) {
+struct TriHead { float t, x1; V3 ap; };
+DEV TriHead tri_head(V3 o, V3 d, const TriFront& f, float4 t0, float4 t1, float4 t2, float x1_max, Mask& out) {
     const V3 n{t0.w, t1.w, t2.w};
     TriHead h;
     h.t = divide_in_range(f.num, f.dn);
     const V3 p = add(o, scale(h.t, d));
     h.ap = sub(p, xyz(t0));
-    h.a1 = vdot(vcross(xyz(t1), h.ap), n) * y;
-    out |= ballot(!(h.t >= TOL)) | ballot(h.a1 < -BARY_TINY) | ballot(h.a1 > 1.0f + BARY_BAND);
+    h.x1 = vdot(vcross(xyz(t1), h.ap), n);
+#if RT_HEAD_T_TEST
+    out |= ballot(!(h.t >= TOL));
+#endif
+    out |= ballot(h.x1 < -X1_TINY) | ballot(h.x1 > x1_max);
     return h;
 }
 // `out`: this lane is among those the earlier stages rejected
 DEV float tri_tail(const TriHead& h, bool out, float4 t0, float4 t1, float4 t2, float y, bool& unsure) {
     const V3 n{t0.w, t1.w, t2.w};
+    const float a1 = h.x1 * y;
     const float b1 = vdot(vcross(h.ap, xyz(t2)), n) * y;
-    const float sum = h.a1 + b1;
-    out = out | (b1 < -BARY_TINY) | (sum > 1.0f + BARY_BAND);
-    const bool in = (h.a1 > BARY_TINY) & (b1 > BARY_TINY) & (sum < 1.0f - BARY_BAND);
+    const float sum = a1 + b1;
+    out = out | !(h.t >= TOL) | (a1 < -BARY_TINY) | (a1 > 1.0f + BARY_BAND) | (b1 < -BARY_TINY) | (sum > 1.0f + BARY_BAND);
+    const bool in = (a1 > BARY_TINY) & (b1 > BARY_TINY) & (sum < 1.0f - BARY_BAND);
     unsure = !(out | in);
     return out ? FLT_MAX : h.t;
 }
@@ -726,9 +742,9 @@ DEV void block_add_stat(unsigned long long* stat, unsigned long long value) {
 // ------------------------------------------------------------------------------------------
 // scene preparation: reference AoSoA-8 -> scan-ordered records
 // ------------------------------------------------------------------------------------------
-// Full-test record of one triangle: (a, n.x) (a_to_b, n.y) (a_to_c, n.z) (n.n, y, 0, 0) with n = a_to_b x a_to_c
-// and n.n as ray_tracing.cpp:131,148 compute them, and y = RN(1/n.n) for the staged form of the test
-// (tri_head), NaN where that form is not proven.
+// Full-test record of one triangle: (a, n.x) (a_to_b, n.y) (a_to_c, n.z) (n.n, y, 0, x1_max) with n = a_to_b x a_to_c
+// and n.n as ray_tracing.cpp:131,148 compute them, and y = RN(1/n.n), x1_max = RN(n.n * (1 + 2^-20)) for the staged
+// form of the test (tri_tail, tri_head), both NaN where that form is not proven.
 DEV void make_tri_record(V3 a, V3 ab, V3 ac, float4* o) {
     const V3 n = vcross(ab, ac);
     const float nn = vdot(n, n);
@@ -738,7 +754,7 @@ DEV void make_tri_record(V3 a, V3 ab, V3 ac, float4* o) {
     const float coord_max = fmaxf(fmaxf(fabsf(a.x), fmaxf(fabsf(a.y), fabsf(a.z))),
                                   fmaxf(fmaxf(fabsf(ab.x), fmaxf(fabsf(ab.y), fabsf(ab.z))), fmaxf(fabsf(ac.x), fmaxf(fabsf(ac.y), fabsf(ac.z)))));
     const bool regular = coord_max <= TAME_COORD && nn >= 8.673617379884035e-19f && nn <= 1.152921504606847e18f;   // 2^-60, 2^60
-    o[3] = make_float4(nn, regular ? 1.0f / nn : __builtin_nanf(""), 0.0f, 0.0f);
+    o[3] = make_float4(nn, regular ? 1.0f / nn : __builtin_nanf(""), 0.0f, regular ? nn * (1.0f + BARY_BAND) : __builtin_nanf(""));
 }
 __global__ void __launch_bounds__(BLOCK) k_prep_triangles(const float* __restrict__ tri8, uint32_t nb, float4* __restrict__ out, float4* __restrict__ outf) {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
@@ -1225,6 +1241,20 @@ DEV void stage_tile(float4* lds, const float4* __restrict__ src, uint32_t first,
     const float4* g = src + static_cast<size_t>(first) * WORDS;
     for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) lds[i] = g[i];
 }
+// The same for full-test records of triangles; true if this thread copied a record that is outside the range the
+// staged form of the test is proven for (make_tri_record marks it with NaN): the workgroup then takes the whole tile
+// through the test as written.
+DEV bool stage_triangle_tile(float4* lds, const float4* __restrict__ src, uint32_t first, uint32_t count) {
+    const uint32_t n4 = count * 4;
+    const float4* g = src + static_cast<size_t>(first) * 4;
+    bool marked = false;
+    for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) {
+        const float4 v = g[i];
+        lds[i] = v;
+        marked = marked || ((i & 3u) == 3u && !(v.w == v.w));
+    }
+    return marked;
+}
 
 // rays base + r*BLOCK + thread of the live list; lanes past the end repeat the first ray and are not stored
 template <int R>
@@ -1385,14 +1415,23 @@ DEV float pretests_then_full(const DevScene& sc, const TriPair& f, V3 o, V3 d, u
 // (RT_FLAG_PLAIN_TEST, and waves that hold a ray outside the range the staged form is proven for).
 // `limit[r]`: a result counts only below it (FLT_MAX for closest-hit rays, the light's distance for
 // shadow rays toward a point light).  visit(r, k, t) is called, for all lanes of the wave at once,
-// when some lane may have a result for ray r; lanes without one see FLT_MAX.
+// when some lane may have a result for ray r; lanes without one see FLT_MAX.  `everyone`: the lanes
+// whose results the caller uses; what the others get is unspecified (a stage is skipped when none
+// of these lanes needs it).
 template <int R, bool STAGED, bool SHARED, typename Visit>
-DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, const V3 (&o)[R], const V3 (&d)[R], bool staged_wave, Visit&& visit) {
+DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, const V3 (&o)[R], const V3 (&d)[R], bool staged_wave, Mask everyone, Visit&& visit) {
     if (STAGED && staged_wave) {
-        const Mask everyone = ballot(true);
         const uint32_t lane = threadIdx.x & 63u;
+#if RT_PREFETCH_RECORD
+        float4 n0 = lds[0], n1 = lds[1], n2 = lds[2], n3 = lds[3];
+#endif
         for (uint32_t k = 0; k < count; ++k) {
+#if RT_PREFETCH_RECORD
+            const float4 t0 = n0, t1 = n1, t2 = n2, t3 = n3;
+            { const uint32_t kn = k + 1 < count ? k + 1 : k; n0 = lds[kn * 4]; n1 = lds[kn * 4 + 1]; n2 = lds[kn * 4 + 2]; n3 = lds[kn * 4 + 3]; }
+#else
             const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
+#endif
             TriFront front[R];
             Mask out[R], in_play = 0;
 #pragma unroll
@@ -1404,13 +1443,13 @@ DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, con
             TriHead head[R];
             in_play = 0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { head[r] = tri_head(o[r], d[r], front[r], t0, t1, t2, t3.y, out[r]); in_play |= everyone & ~out[r]; }
+            for (int r = 0; r < R; ++r) { head[r] = tri_head(o[r], d[r], front[r], t0, t1, t2, t3.w, out[r]); in_play |= everyone & ~out[r]; }
             if (in_play == 0) continue;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 bool unsure;
                 float t = tri_tail(head[r], ((out[r] >> lane) & 1ull) != 0ull, t0, t1, t2, t3.y, unsure);
-                if (__any(unsure)) t = hit_triangle(o[r], d[r], t0, t1, t2, t3.x);
+                if ((ballot(unsure) & everyone) != 0) t = hit_triangle(o[r], d[r], t0, t1, t2, t3.x);
                 visit(r, first + k, t);
             }
         }
@@ -1469,17 +1508,17 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri_brute(DevScene sc, State 
     auto visit = [&](int r, uint32_t k, float t) __attribute__((always_inline)) {
         if (t < best_t[r]) { best_t[r] = t; best_k[r] = k; }
     };
+    const Mask everyone = ballot(true);
     for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
         __syncthreads();
-        stage_tile<4>(lds, sc.tri, first, count);
-        __syncthreads();
-        if (shared_origin) {
+        const bool as_written = __syncthreads_or(stage_triangle_tile(lds, sc.tri, first, count));
+        if (shared_origin && !as_written) {
             tile_shared_numerators(lds, count, o_block);
             __syncthreads();
-            brute_force_tile<R, STAGED, true>(lds, first, count, o, d, staged_wave, visit);
+            brute_force_tile<R, STAGED, true>(lds, first, count, o, d, staged_wave, everyone, visit);
         } else {
-            brute_force_tile<R, STAGED, false>(lds, first, count, o, d, staged_wave, visit);
+            brute_force_tile<R, STAGED, false>(lds, first, count, o, d, staged_wave && !as_written, everyone, visit);
         }
     }
 #pragma unroll
@@ -2139,82 +2178,115 @@ DEV ShadowRay make_shadow_ray(const State& st, uint32_t slot, bool point, V3 lv)
 }
 
 // Brute-force any-hit over the triangle list toward light first_light + blockIdx.y (see k_closest_tri_brute), one ray per lane.
-// A blocked ray needs no further tests, but its lane keeps executing while any ray of its wave is still open, and in a
-// dense scene most rays are blocked somewhere along the list.  Every SHADOW_COMPACT_TILES tiles the workgroup therefore
-// packs its open rays into as few waves as they fill (ray data parked in LDS, ids compacted in order with ballots);
-// waves left without rays only take part in the staging and the barriers.  The result does not depend on which lane
-// tests a ray: "blocked" is an OR over the triangles.
+// A blocked ray needs no further tests, and in a dense scene most rays are blocked somewhere along the list: a lane
+// whose ray is blocked, or has seen the whole list, takes another ray.  "Blocked" is an OR over the triangles, so a
+// ray may start anywhere in the list: the workgroup stages the tiles of the list round and round, a ray that joins at
+// tile s is tested against tiles s, s+1, ... up to s-1, and every lane counts the tiles its ray has still to see.
+// A workgroup owns a contiguous range of the ray list, SHADOW_RANGE_BLOCKS x BLOCK rays (fewer when the launch would
+// otherwise have fewer than SHADOW_MIN_RANGES ranges over all lights): every SHADOW_COMPACT_TILES tiles it retires the
+// rays that are done, moves the open ones to the first lanes (ray data passed through LDS, order kept) and fills the
+// lanes behind them with the next rays of its range.  Waves left without rays at the end of the range only take part
+// in the staging and the barriers, beside the other workgroups of their CU.  Neighbours in the list are neighbours in
+// the image, so the rays of a wave agree on most triangles and whole stages of the test are skipped; handing out rays
+// from one cursor per launch instead keeps every lane busy to the end but mixes rays from all over the image in a wave
+// (measured: 0.51 of the FP32 peak against 0.57 with ranges).
 #ifndef RT_SHADOW_COMPACT_TILES
 #define RT_SHADOW_COMPACT_TILES 4
 #endif
-constexpr uint32_t SHADOW_COMPACT_TILES = RT_SHADOW_COMPACT_TILES;
+#ifndef RT_SHADOW_RANGE_BLOCKS
+#define RT_SHADOW_RANGE_BLOCKS 16
+#endif
+#ifndef RT_SHADOW_MIN_RANGES
+#define RT_SHADOW_MIN_RANGES 6144
+#endif
+constexpr uint32_t SHADOW_COMPACT_TILES = RT_SHADOW_COMPACT_TILES, SHADOW_RANGE_BLOCKS = RT_SHADOW_RANGE_BLOCKS, SHADOW_MIN_RANGES = RT_SHADOW_MIN_RANGES;
 template <bool STAGED>
 __global__ void __launch_bounds__(BLOCK) k_shadow_tri_brute(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
     __shared__ float4 lds[TILE_PRIMS * 4];
-    __shared__ float4 parked[2][BLOCK];        // (o, limit) (d, -) of the workgroup's rays, by ray number
-    __shared__ uint32_t ray_blocked[BLOCK];    // by ray number
-    __shared__ uint32_t open_ids[BLOCK];       // the open rays' numbers, packed
+    __shared__ float4 parked[2][BLOCK];        // (o, limit) (d, tiles left) of the rays the workgroup holds, by lane
+    __shared__ uint32_t parked_slot[BLOCK];
     __shared__ uint32_t wave_open[BLOCK / 64];
     const uint32_t n_rays = st.counts[bounce + 1];
-    const uint32_t base = blockIdx.x * BLOCK;
-    if (base >= n_rays) return;
+    const uint32_t n_blocks = (n_rays + BLOCK - 1) / BLOCK;
+    const uint32_t blocks_per_wg = min(SHADOW_RANGE_BLOCKS, max(1u, n_blocks * gridDim.y / SHADOW_MIN_RANGES));
+    if (static_cast<unsigned long long>(blockIdx.x) * blocks_per_wg >= n_blocks) return;      // (also: no rays)
+    uint32_t range_next = blockIdx.x * blocks_per_wg * BLOCK;                                 // the next ray of the range
+    const uint32_t range_end = static_cast<uint32_t>(min(static_cast<unsigned long long>(n_rays), static_cast<unsigned long long>(range_next) + static_cast<unsigned long long>(blocks_per_wg) * BLOCK));
+    const uint32_t* __restrict__ list_in = st.list[(bounce + 1) & 1u];
     const float* __restrict__ L = sc.lights + (first_light + blockIdx.y) * 8;
+    const bool point = L[0] != 0.0f;
+    const V3 lv{L[1], L[2], L[3]};
     const uint32_t light_bit = 1u << (first_light + blockIdx.y - group_first);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    ShadowRays<1> own;                         // this thread's own ray: number threadIdx.x
-    load_shadow_rays<1>(st, st.list[(bounce + 1) & 1u], base, n_rays, L[0] != 0.0f, V3{L[1], L[2], L[3]}, light_bit, own);
-    parked[0][threadIdx.x] = make_float4(own.o[0].x, own.o[0].y, own.o[0].z, own.limit[0]);
-    parked[1][threadIdx.x] = make_float4(own.d[0].x, own.d[0].y, own.d[0].z, 0.0f);
-    ray_blocked[threadIdx.x] = (own.blocked[0] || !own.valid[0]) ? 1u : 0u;
-    // the ray this lane is testing now: `mine` (a ray number), open while `active`
-    uint32_t mine = threadIdx.x;
-    bool active = own.valid[0] && !own.blocked[0];
-    V3 o[1] = {own.o[0]}, d[1] = {own.d[0]};
-    float limit = own.limit[0];
-    bool blocked = false;
-    bool staged_wave = __all(ray_is_tame(o[0], d[0]));
+    const uint32_t n_tiles = (sc.n_tri + TILE_PRIMS - 1) / TILE_PRIMS;
+    const uint32_t interval = min(SHADOW_COMPACT_TILES, n_tiles);
+    // the ray this lane is testing: open while `active`, not blocked and with tiles left to see
+    uint32_t slot = 0, left = 0;
+    bool active = false, blocked = false;
+    V3 o[1] = {V3{0.0f, 0.0f, 0.0f}}, d[1] = {V3{0.0f, 0.0f, 0.0f}};
+    float limit = 0.0f;
+    bool staged_wave = false;
+    uint32_t held = 0;                         // lanes [0, held) hold a ray
+    uint32_t tile = 0;                         // the tile of the list that is staged next
     unsigned long long wave_tests = 0;
-    uint32_t tile = 0;
-    for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS, ++tile) {
-        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
-        if (tile % SHADOW_COMPACT_TILES == 0) {
-            // pack the open rays: results so far, then the open ones' numbers in order, then every lane takes its new ray
-            if (active && blocked) ray_blocked[mine] = 1u;
-            const bool open = active && !blocked;
-            const Mask open_mask = ballot(open);
-            if (lane == 0) wave_open[wave] = static_cast<uint32_t>(__popcll(open_mask));
-            __syncthreads();
-            uint32_t before = 0, total = 0;
+    for (;;) {
+        // retire what is done, pack the open rays in order, take new ones
+        if (active && blocked) atomicOr(&st.blocked[slot], light_bit);
+        const bool open = active && !blocked && left != 0u;
+        const Mask open_mask = ballot(open);
+        if (lane == 0) wave_open[wave] = static_cast<uint32_t>(__popcll(open_mask));
+        __syncthreads();
+        uint32_t before = 0, total = 0;
 #pragma unroll
-            for (uint32_t w = 0; w < BLOCK / 64; ++w) { const uint32_t c = wave_open[w]; before += w < wave ? c : 0u; total += c; }
-            if (total == 0) break;                                     // uniform over the workgroup
-            if (open) open_ids[before + static_cast<uint32_t>(__popcll(open_mask & ((1ull << lane) - 1ull)))] = mine;
+        for (uint32_t w = 0; w < BLOCK / 64; ++w) { const uint32_t c = wave_open[w]; before += w < wave ? c : 0u; total += c; }
+        const uint32_t room = static_cast<uint32_t>(BLOCK) - total;
+        const uint32_t next = range_next;
+        const uint32_t take = min(room, range_end - range_next);
+        range_next += take;
+        if (total + take == 0) break;                                  // uniform over the workgroup: every ray of the range is done
+        if (total != held || take != 0) {                              // uniform
+            if (open) {
+                const uint32_t to = before + static_cast<uint32_t>(__popcll(open_mask & ((1ull << lane) - 1ull)));
+                parked[0][to] = make_float4(o[0].x, o[0].y, o[0].z, limit);
+                parked[1][to] = make_float4(d[0].x, d[0].y, d[0].z, __uint_as_float(left));
+                parked_slot[to] = slot;
+            }
+            if (threadIdx.x >= total && threadIdx.x < total + take) {
+                const uint32_t s = list_in[next + (threadIdx.x - total)];
+                const ShadowRay ray = make_shadow_ray(st, s, point, lv);
+                const bool blocked_before = (st.blocked[s] & light_bit) != 0u;         // (by a scan of another kind of primitive)
+                parked[0][threadIdx.x] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.limit);
+                parked[1][threadIdx.x] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(blocked_before ? 0u : n_tiles));
+                parked_slot[threadIdx.x] = s;
+            }
             __syncthreads();
-            // lanes past the open rays of a partly filled wave repeat that wave's first ray (their results are dropped), so
-            // that they do not disturb the wave's common decisions; waves without any ray skip the tests
+            held = total + take;
+            // lanes past the rays of a partly filled wave repeat that wave's first ray (their results are dropped), so
+            // that they meet no operands of their own; waves without any ray skip the tests
             const uint32_t wave_first = wave * 64u;
-            active = threadIdx.x < total;
-            const uint32_t take = active ? threadIdx.x : (wave_first < total ? wave_first : 0u);
-            mine = open_ids[take];
-            const float4 p0 = parked[0][mine], p1 = parked[1][mine];
-            o[0] = xyz(p0); d[0] = xyz(p1); limit = p0.w;
+            active = threadIdx.x < held;
+            const uint32_t from = active ? threadIdx.x : (wave_first < held ? wave_first : 0u);
+            const float4 p0 = parked[0][from], p1 = parked[1][from];
+            o[0] = xyz(p0); d[0] = xyz(p1); limit = p0.w; left = __float_as_uint(p1.w); slot = parked_slot[from];
             blocked = false;
             staged_wave = __all(ray_is_tame(o[0], d[0]));
         }
-        __syncthreads();
-        stage_tile<4>(lds, sc.tri, first, count);
-        __syncthreads();
-        const Mask testing = ballot(active && !blocked);
-        if (testing != 0) {
-            wave_tests += static_cast<unsigned long long>(count) * static_cast<uint32_t>(__popcll(testing));
-            brute_force_tile<1, STAGED, false>(lds, first, count, o, d, staged_wave, [&](int, uint32_t, float t) __attribute__((always_inline)) {
-                blocked |= t < limit;
-            });
+        for (uint32_t step = 0; step < interval; ++step) {
+            const uint32_t first = tile * TILE_PRIMS;
+            const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
+            __syncthreads();
+            const bool as_written = __syncthreads_or(stage_triangle_tile(lds, sc.tri, first, count));
+            const Mask testing = ballot(active && !blocked && left != 0u);
+            if (testing != 0) {
+                wave_tests += static_cast<unsigned long long>(count) * static_cast<uint32_t>(__popcll(testing));
+                brute_force_tile<1, STAGED, false>(lds, first, count, o, d, staged_wave && !as_written, testing, [&](int, uint32_t, float t) __attribute__((always_inline)) {
+                    blocked |= t < limit;
+                });
+            }
+            left -= left != 0u ? 1u : 0u;
+            tile = tile + 1 == n_tiles ? 0u : tile + 1;
         }
     }
-    if (active && blocked) ray_blocked[mine] = 1u;
-    __syncthreads();
-    if (own.valid[0] && !own.blocked[0] && ray_blocked[threadIdx.x]) atomicOr(&st.blocked[own.slot[0]], light_bit);
     if (lane == 0 && wave_tests) atomicAdd(stat_slot(st, ST_SHADOW_TESTS_TRI), wave_tests);
 }
 
@@ -2806,10 +2878,10 @@ __global__ void __launch_bounds__(BLOCK) k_debug_eval(int op, uint32_t n, const 
         make_tri_record(V3{a[j * 9], a[j * 9 + 1], a[j * 9 + 2]}, V3{a[j * 9 + 3], a[j * 9 + 4], a[j * 9 + 5]}, V3{a[j * 9 + 6], a[j * 9 + 7], a[j * 9 + 8]}, rec);
         const V3 o{b[j * 6], b[j * 6 + 1], b[j * 6 + 2]}, d{b[j * 6 + 3], b[j * 6 + 4], b[j * 6 + 5]};
         float t = hit_triangle(o, d, rec[0], rec[1], rec[2], rec[3].x);
-        if (op == RT_DEBUG_TRIANGLE_STAGED && ray_is_tame(o, d)) {
+        if (op == RT_DEBUG_TRIANGLE_STAGED && ray_is_tame(o, d) && rec[3].w == rec[3].w) {   // (the scans take rays and records outside the staged form's range through the test as written)
             Mask out_mask;
             const TriFront front = tri_front(o, d, rec[0], rec[1], rec[2], out_mask);
-            const TriHead head = tri_head(o, d, front, rec[0], rec[1], rec[2], rec[3].y, out_mask);
+            const TriHead head = tri_head(o, d, front, rec[0], rec[1], rec[2], rec[3].w, out_mask);
             bool unsure;
             const float staged = tri_tail(head, ((out_mask >> (threadIdx.x & 63u)) & 1ull) != 0ull, rec[0], rec[1], rec[2], rec[3].y, unsure);
             // an unsure pair reports NaN: the scans run the plain form for it, and the test counts such pairs
@@ -3340,7 +3412,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                     const uint32_t n_pt = group - n_dir;
                     // brute-force shadow scan of one kind toward lights first.. (n of them)
                     auto brute_force = [&](int prim, uint32_t n, uint32_t first_light) {
-                        const dim3 grid(prim == 0 ? ray_blocks() : scan_blocks(), n);    // the triangle scan takes one ray per lane
+                        const dim3 grid(prim == 0 ? ray_blocks() : scan_blocks(), n);    // the triangle scan takes one ray per lane (and cuts the list into ranges of its own: a workgroup beyond the last range returns)
                         if (prim == 0 && plain_test) hipLaunchKernelGGL((k_shadow_tri_brute<false>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                         else if (prim == 0) hipLaunchKernelGGL((k_shadow_tri_brute<true>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                         else if (prim == 1) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);

@@ -104,7 +104,7 @@ def main():
             kind = "front: d.n%s, parallel test" % (" ((a-o).n comes with the record: rays with one origin)" if shared else ", (a-o).n, sign test (any rays)")
             variant = "one origin" if shared else "any rays"
         elif has_rcp and not has_div and previous.startswith("front"):
-            kind = "head: in-range division, hit point, alpha numerator, three comparisons"
+            kind = "head: in-range division, hit point, alpha numerator, two comparisons"
         elif not has_rcp and not has_div and previous.startswith("head"):
             kind = "tail: beta numerator, sums, comparisons (only when a lane is still in play)"
         elif has_div and previous.startswith("tail"):
