@@ -386,7 +386,8 @@ def brute_force_leg(abi, fi, cam, scene, depth, args, label):
                 "stages that skip what the outcome does not depend on (results identical to the test as written, which --plain-test runs)",
         "sample": "centred %dx%d-pixel crop of %s, maxdepth %d: %d closest-hit rays, %d shadow rays, %d triangles" % (cw, ch, label, depth, st.closest_rays, st.shadow_rays, n_tri),
         "shadow_kernel": dict(shadow, traffic=measured.get("shadow_hbm_bytes_per_launch"), valu_issue_utilisation=measured.get("shadow_valu_issue_utilisation"),
-                              pairs_counted="primitives scanned while the ray was still unblocked"),
+                              pairs_counted="triangles staged while the ray was still open (a ray joins the list at the tile its workgroup has reached, goes once round and leaves at the first "
+                                            "refill after it is blocked)"),
         "dominant_by_time": "k_shadow_tri_brute" if st.shadow_kind_ms[0] > st.closest_kind_ms[0] else "k_closest_tri_brute",
         "other_kinds_ms": {"closest_sphere": st.closest_kind_ms[1], "closest_ellipsoid": st.closest_kind_ms[2], "shadow_sphere": st.shadow_kind_ms[1], "shadow_ellipsoid": st.shadow_kind_ms[2]},
         "leg_device_ms": st.device_ms,

@@ -125,7 +125,8 @@ typedef struct rt_stats {
                                      With RT_FLAG_NO_FILTER every pair is visited by a brute-force scan; in the default mode the
                                      bounding hierarchy decides most pairs without visiting them (pair_pretests, queued_pairs and
                                      full_tests count what was executed) */
-    uint64_t shadow_tests[3];     /* ray-primitive tests, shadow rays, up to the point the ray's wave stopped scanning */
+    uint64_t shadow_tests[3];     /* ray-primitive tests, shadow rays, up to the point the ray's wave stopped scanning (brute-force
+                                     triangle scan: up to the tile after which the ray's lane was given another ray) */
     double   device_ms;           /* HIP-event time of all launches of this call */
     double   closest_ms;          /* HIP-event time summed over the closest-hit scan launches */
     double   shadow_ms;           /* HIP-event time summed over the shadow scan launches */

@@ -319,12 +319,6 @@ DEV float hit_triangle(V3 o, V3 d, float4 t0, float4 t1, float4 t2, float nn) {
 constexpr float BARY_TINY = 1.0e-30f;
 constexpr float BARY_BAND = 9.5367431640625e-7f;   // 2^-20
 constexpr float X1_TINY = 8.673617379884035e-19f;  // 2^-60
-#ifndef RT_PREFETCH_RECORD
-#define RT_PREFETCH_RECORD 0
-#endif
-#ifndef RT_HEAD_T_TEST
-#define RT_HEAD_T_TEST 0
-#endif
 constexpr float TAME_COORD = 4096.0f;
 DEV bool ray_is_tame(V3 o, V3 d) {
     return fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))) <= TAME_COORD && fmaxf(fabsf(d.x), fmaxf(fabsf(d.y), fabsf(d.z))) <= 2.0f;
@@ -376,9 +370,6 @@ DEV TriHead tri_head(V3 o, V3 d, const TriFront& f, float4 t0, float4 t1, float4
     const V3 p = add(o, scale(h.t, d));
     h.ap = sub(p, xyz(t0));
     h.x1 = vdot(vcross(xyz(t1), h.ap), n);
-#if RT_HEAD_T_TEST
-    out |= ballot(!(h.t >= TOL));
-#endif
     out |= ballot(h.x1 < -X1_TINY) | ballot(h.x1 > x1_max);
     return h;
 }
@@ -1241,19 +1232,31 @@ DEV void stage_tile(float4* lds, const float4* __restrict__ src, uint32_t first,
     const float4* g = src + static_cast<size_t>(first) * WORDS;
     for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) lds[i] = g[i];
 }
-// The same for full-test records of triangles; true if this thread copied a record that is outside the range the
-// staged form of the test is proven for (make_tri_record marks it with NaN): the workgroup then takes the whole tile
-// through the test as written.
-DEV bool stage_triangle_tile(float4* lds, const float4* __restrict__ src, uint32_t first, uint32_t count) {
-    const uint32_t n4 = count * 4;
-    const float4* g = src + static_cast<size_t>(first) * 4;
-    bool marked = false;
-    for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) {
-        const float4 v = g[i];
-        lds[i] = v;
-        marked = marked || ((i & 3u) == 3u && !(v.w == v.w));
-    }
-    return marked;
+// A tile of full-test records of triangles, one triangle per thread, laid out for the order in which the staged
+// test wants the words: four arrays of TILE_PRIMS float4,
+//   [0] (n, (a-o).n)   [1] (a, x1_max)   [2] (a_to_b, y)   [3] (a_to_c, n.n)
+// so that a step that ends at the front reads 16 bytes of the record (rays with one origin; 32 otherwise), one that
+// ends at the head 48, and only the tail and the test as written all 64.  (a-o).n is computed here, with the very
+// expression of tri_front, when all rays of the workgroup start at `o` (`shared`: rays from the eye); else the word
+// is unused.  Returns true if this thread's record is outside the range the staged form of the test is proven for
+// (make_tri_record marks it with NaN): the workgroup then takes the whole tile through the test as written.
+static_assert(TILE_PRIMS == BLOCK, "stage_triangle_tile: one triangle per thread");
+DEV bool stage_triangle_tile(float4* lds, const float4* __restrict__ src, uint32_t first, uint32_t count, bool shared, V3 o) {
+    if (threadIdx.x >= count) return false;
+    const float4* g = src + static_cast<size_t>(first + threadIdx.x) * 4;
+    const float4 t0 = g[0], t1 = g[1], t2 = g[2], t3 = g[3];
+    const V3 n{t0.w, t1.w, t2.w};
+    lds[threadIdx.x] = make_float4(n.x, n.y, n.z, shared ? vdot(sub(xyz(t0), o), n) : 0.0f);
+    lds[TILE_PRIMS + threadIdx.x] = make_float4(t0.x, t0.y, t0.z, t3.w);
+    lds[2 * TILE_PRIMS + threadIdx.x] = make_float4(t1.x, t1.y, t1.z, t3.y);
+    lds[3 * TILE_PRIMS + threadIdx.x] = make_float4(t2.x, t2.y, t2.z, t3.x);
+    return !(t3.w == t3.w);
+}
+// record k of such a tile in the words of make_tri_record: (a, n.x) (a_to_b, n.y) (a_to_c, n.z) (n.n, y, (a-o).n, x1_max)
+struct TileTriangle { float4 t0, t1, t2, t3; };
+DEV TileTriangle tile_triangle(const float4* lds, uint32_t k) {
+    const float4 r0 = lds[k], r1 = lds[TILE_PRIMS + k], r2 = lds[2 * TILE_PRIMS + k], r3 = lds[3 * TILE_PRIMS + k];
+    return TileTriangle{make_float4(r1.x, r1.y, r1.z, r0.x), make_float4(r2.x, r2.y, r2.z, r0.y), make_float4(r3.x, r3.y, r3.z, r0.z), make_float4(r3.w, r2.w, r0.w, r1.w)};
 }
 
 // rays base + r*BLOCK + thread of the live list; lanes past the end repeat the first ray and are not stored
@@ -1418,20 +1421,35 @@ DEV float pretests_then_full(const DevScene& sc, const TriPair& f, V3 o, V3 d, u
 // when some lane may have a result for ray r; lanes without one see FLT_MAX.  `everyone`: the lanes
 // whose results the caller uses; what the others get is unspecified (a stage is skipped when none
 // of these lanes needs it).
+#ifndef RT_PIN_READS
+#define RT_PIN_READS 1
+#endif
+#if RT_PIN_READS
+#define PIN(v) asm volatile("" : "+v"(v))
+#else
+#define PIN(v) (void)(v)
+#endif
 template <int R, bool STAGED, bool SHARED, typename Visit>
 DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, const V3 (&o)[R], const V3 (&d)[R], bool staged_wave, Mask everyone, Visit&& visit) {
     if (STAGED && staged_wave) {
         const uint32_t lane = threadIdx.x & 63u;
-#if RT_PREFETCH_RECORD
-        float4 n0 = lds[0], n1 = lds[1], n2 = lds[2], n3 = lds[3];
-#endif
         for (uint32_t k = 0; k < count; ++k) {
-#if RT_PREFETCH_RECORD
-            const float4 t0 = n0, t1 = n1, t2 = n2, t3 = n3;
-            { const uint32_t kn = k + 1 < count ? k + 1 : k; n0 = lds[kn * 4]; n1 = lds[kn * 4 + 1]; n2 = lds[kn * 4 + 2]; n3 = lds[kn * 4 + 3]; }
-#else
-            const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
-#endif
+            // Each of the four parts is read where it is first used, as one 16-byte read (left alone the compiler reads the
+            // words it needs: 12-byte and strided reads, which take the LDS twice as long).
+            // The position in the tile is made opaque before each stage (RT_PIN_READS), so that the reads of a stage
+            // cannot be moved ahead of the branch before it: a step that ends at the front then costs the LDS one read.
+            uint32_t kv = k * static_cast<uint32_t>(sizeof(float4));
+            PIN(kv);
+            const auto part = [&](uint32_t j) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(lds + j * TILE_PRIMS) + kv); };
+            const float4 r0 = part(0);
+            float4 r1;
+            if (!SHARED) r1 = part(1);
+            asm volatile("" : : "v"(r0.x), "v"(r0.y), "v"(r0.z), "v"(r0.w));
+            if (!SHARED) asm volatile("" : : "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w));
+            float4 t0, t1, t2, t3;
+            t0.w = r0.x; t1.w = r0.y; t2.w = r0.z; t3.z = r0.w;
+            if (!SHARED) { t0.x = r1.x; t0.y = r1.y; t0.z = r1.z; t3.w = r1.w; }
+            t1.x = t1.y = t1.z = t2.x = t2.y = t2.z = t3.x = t3.y = 0.0f;   // (not read before the head)
             TriFront front[R];
             Mask out[R], in_play = 0;
 #pragma unroll
@@ -1440,11 +1458,20 @@ DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, con
                 in_play |= everyone & ~out[r];
             }
             if (in_play == 0) continue;
+            PIN(kv);
+            if (SHARED) { r1 = part(1); asm volatile("" : : "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w)); t0.x = r1.x; t0.y = r1.y; t0.z = r1.z; t3.w = r1.w; }
+            const float4 r2 = part(2);
+            asm volatile("" : : "v"(r2.x), "v"(r2.y), "v"(r2.z), "v"(r2.w));
+            t1.x = r2.x; t1.y = r2.y; t1.z = r2.z; t3.y = r2.w;
             TriHead head[R];
             in_play = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) { head[r] = tri_head(o[r], d[r], front[r], t0, t1, t2, t3.w, out[r]); in_play |= everyone & ~out[r]; }
             if (in_play == 0) continue;
+            PIN(kv);
+            const float4 r3 = part(3);
+            asm volatile("" : : "v"(r3.x), "v"(r3.y), "v"(r3.z), "v"(r3.w));
+            t2.x = r3.x; t2.y = r3.y; t2.z = r3.z; t3.x = r3.w;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 bool unsure;
@@ -1456,28 +1483,19 @@ DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, con
     } else if constexpr (STAGED) {   // a wave with a ray outside the staged form's range: rare, kept small
 #pragma nounroll
         for (uint32_t k = 0; k < count; ++k) {
-            const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
+            const TileTriangle tt = tile_triangle(lds, k);
 #pragma unroll
-            for (int r = 0; r < R; ++r) visit(r, first + k, hit_triangle(o[r], d[r], t0, t1, t2, t3.x));
+            for (int r = 0; r < R; ++r) visit(r, first + k, hit_triangle(o[r], d[r], tt.t0, tt.t1, tt.t2, tt.t3.x));
         }
     } else {
 #pragma unroll 2
         for (uint32_t k = 0; k < count; ++k) {
-            const float4 t0 = lds[k * 4], t1 = lds[k * 4 + 1], t2 = lds[k * 4 + 2], t3 = lds[k * 4 + 3];
+            const TileTriangle tt = tile_triangle(lds, k);
 #pragma unroll
-            for (int r = 0; r < R; ++r) visit(r, first + k, hit_triangle(o[r], d[r], t0, t1, t2, t3.x));
+            for (int r = 0; r < R; ++r) visit(r, first + k, hit_triangle(o[r], d[r], tt.t0, tt.t1, tt.t2, tt.t3.x));
         }
     }
 }
-// (a-o).n of every triangle of the staged tile for the origin o all rays of the workgroup share, into the
-// record's spare word [3].z; one triangle per thread, between two barriers of the caller.
-DEV void tile_shared_numerators(float4* lds, uint32_t count, V3 o) {
-    if (threadIdx.x < count) {
-        const float4 t0 = lds[threadIdx.x * 4], t1 = lds[threadIdx.x * 4 + 1], t2 = lds[threadIdx.x * 4 + 2];
-        reinterpret_cast<float*>(lds + threadIdx.x * 4 + 3)[2] = vdot(sub(xyz(t0), o), V3{t0.w, t1.w, t2.w});
-    }
-}
-
 template <int R, bool STAGED>
 __global__ void __launch_bounds__(BLOCK) k_closest_tri_brute(DevScene sc, State st, uint32_t bounce) {
     __shared__ float4 lds[TILE_PRIMS * 4];
@@ -1493,7 +1511,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri_brute(DevScene sc, State 
 #pragma unroll
     for (int r = 0; r < R; ++r) { best_t[r] = FLT_MAX; best_k[r] = 0xFFFFFFFFu; tame = tame && ray_is_tame(o[r], d[r]); }
     const bool staged_wave = __all(tame);
-    // rays from the eye share their origin: then (a-o).n is computed once per triangle and tile, not once per pair
+    // rays from the eye share their origin: then (a-o).n is computed once per triangle and tile (stage_triangle_tile), not once per pair
     bool same = true;
 #pragma unroll
     for (int r = 0; r < R; ++r) same = same && o[r].x == o[0].x && o[r].y == o[0].y && o[r].z == o[0].z;
@@ -1512,10 +1530,8 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri_brute(DevScene sc, State 
     for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
         __syncthreads();
-        const bool as_written = __syncthreads_or(stage_triangle_tile(lds, sc.tri, first, count));
+        const bool as_written = __syncthreads_or(stage_triangle_tile(lds, sc.tri, first, count, shared_origin, o_block));
         if (shared_origin && !as_written) {
-            tile_shared_numerators(lds, count, o_block);
-            __syncthreads();
             brute_force_tile<R, STAGED, true>(lds, first, count, o, d, staged_wave, everyone, visit);
         } else {
             brute_force_tile<R, STAGED, false>(lds, first, count, o, d, staged_wave && !as_written, everyone, visit);
@@ -2275,7 +2291,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tri_brute(DevScene sc, State s
             const uint32_t first = tile * TILE_PRIMS;
             const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
             __syncthreads();
-            const bool as_written = __syncthreads_or(stage_triangle_tile(lds, sc.tri, first, count));
+            const bool as_written = __syncthreads_or(stage_triangle_tile(lds, sc.tri, first, count, false, V3{0.0f, 0.0f, 0.0f}));
             const Mask testing = ballot(active && !blocked && left != 0u);
             if (testing != 0) {
                 wave_tests += static_cast<unsigned long long>(count) * static_cast<uint32_t>(__popcll(testing));
