@@ -1433,17 +1433,24 @@ template <int R, bool STAGED, bool SHARED, typename Visit>
 DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, const V3 (&o)[R], const V3 (&d)[R], bool staged_wave, Mask everyone, Visit&& visit) {
     if (STAGED && staged_wave) {
         const uint32_t lane = threadIdx.x & 63u;
-        for (uint32_t k = 0; k < count; ++k) {
-            // Each of the four parts is read where it is first used, as one 16-byte read (left alone the compiler reads the
-            // words it needs: 12-byte and strided reads, which take the LDS twice as long).
-            // The position in the tile is made opaque before each stage (RT_PIN_READS), so that the reads of a stage
-            // cannot be moved ahead of the branch before it: a step that ends at the front then costs the LDS one read.
+        // Each of the four parts of a record is read as one 16-byte read (left alone the compiler reads the words it needs:
+        // 12-byte and strided reads, which take the LDS twice as long), where its stage begins: the position in the tile
+        // is made opaque before the head and the tail, so that their reads cannot be moved ahead of the branch before
+        // them, and a step that ends at the front costs the LDS one read (two for rays of any origin).  (Reading the
+        // front's parts a step ahead, two triangles per turn of the loop with registers of their own, was measured: the
+        // compiler then waits for every outstanding read at the top of a step, the one just issued included: -1 %.)
+        struct FrontParts { float4 r0, r1; };
+        const auto front_parts = [&](uint32_t k) __attribute__((always_inline)) {
+            FrontParts f;
+            f.r0 = lds[k];
+            f.r1 = SHARED ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : lds[TILE_PRIMS + k];
+            return f;
+        };
+        const auto step = [&](uint32_t k, const FrontParts& fp) __attribute__((always_inline)) {
             uint32_t kv = k * static_cast<uint32_t>(sizeof(float4));
-            PIN(kv);
             const auto part = [&](uint32_t j) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(lds + j * TILE_PRIMS) + kv); };
-            const float4 r0 = part(0);
-            float4 r1;
-            if (!SHARED) r1 = part(1);
+            const float4 r0 = fp.r0;
+            float4 r1 = fp.r1;
             asm volatile("" : : "v"(r0.x), "v"(r0.y), "v"(r0.z), "v"(r0.w));
             if (!SHARED) asm volatile("" : : "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w));
             float4 t0, t1, t2, t3;
@@ -1457,7 +1464,7 @@ DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, con
                 front[r] = SHARED ? tri_front_shared(d[r], t0, t1, t2, t3.z, out[r]) : tri_front(o[r], d[r], t0, t1, t2, out[r]);
                 in_play |= everyone & ~out[r];
             }
-            if (in_play == 0) continue;
+            if (in_play == 0) return;
             PIN(kv);
             if (SHARED) { r1 = part(1); asm volatile("" : : "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w)); t0.x = r1.x; t0.y = r1.y; t0.z = r1.z; t3.w = r1.w; }
             const float4 r2 = part(2);
@@ -1467,7 +1474,7 @@ DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, con
             in_play = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) { head[r] = tri_head(o[r], d[r], front[r], t0, t1, t2, t3.w, out[r]); in_play |= everyone & ~out[r]; }
-            if (in_play == 0) continue;
+            if (in_play == 0) return;
             PIN(kv);
             const float4 r3 = part(3);
             asm volatile("" : : "v"(r3.x), "v"(r3.y), "v"(r3.z), "v"(r3.w));
@@ -1479,7 +1486,8 @@ DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, con
                 if ((ballot(unsure) & everyone) != 0) t = hit_triangle(o[r], d[r], t0, t1, t2, t3.x);
                 visit(r, first + k, t);
             }
-        }
+        };
+        for (uint32_t k = 0; k < count; ++k) step(k, front_parts(k));
     } else if constexpr (STAGED) {   // a wave with a ray outside the staged form's range: rare, kept small
 #pragma nounroll
         for (uint32_t k = 0; k < count; ++k) {
