@@ -149,3 +149,42 @@ def test_coincident_and_collinear_primitives(gpu, oracle, tmp_path):
     text += "pushTransform\ntranslate -1 0.5 1\nscale 0.5 0.3 0.2\n" + "sphere 0 0 0 1\n" * 150 + "popTransform\n"
     o = compare(gpu, oracle, write(tmp_path, "coincident", text))
     assert o["stats"].hits > 0
+
+
+def test_many_lights_and_triangles_outside_the_staged_range(gpu, oracle, tmp_path):
+    """Forty point lights and a directional one (two groups of light bits), 700 small triangles (three tiles of the brute-force
+    scans: fewer than the shadow scan's refill interval) and two triangles outside the range the staged form of the test is
+    proven for, a huge one and a tiny one (their tiles go through the test as written).  Default mode, the walks, brute force
+    with the staged test and with the test as written, all against the oracle."""
+    rng = np.random.default_rng(5)
+    text = "size 56 36\nmaxdepth 2\noutput edge.png\ncamera 0 2 9 0 0 0 0 1 0 40\nambient .05 .05 .05\n"
+    text += "directional 0 -1 -1 .02 .02 .02\n"
+    for i in range(40):
+        a = 2.0 * np.pi * i / 40
+        text += "point %.6f %.6f %.6f .02 .02 .02\n" % (7.0 * np.cos(a), 5.0 + (i % 3), 7.0 * np.sin(a))
+    text += "diffuse .4 .3 .2\nspecular .3 .3 .3\nshininess 15\n" + FLOOR.replace("maxverts 16", "maxverts 4000")
+    n_vertices = 4
+    for _ in range(700):
+        c = rng.uniform([-3.0, -0.5, -3.0], [3.0, 2.5, 3.0])
+        for _ in range(3):
+            v = c + rng.uniform(-0.25, 0.25, 3)
+            text += "vertex %.6f %.6f %.6f\n" % (v[0], v[1], v[2])
+        text += "tri %d %d %d\n" % (n_vertices, n_vertices + 1, n_vertices + 2)
+        n_vertices += 3
+    text += "vertex -9000 -1.5 -9000\nvertex 0 -1.5 9000\nvertex 9000 -1.5 -9000\ntri %d %d %d\n" % (n_vertices, n_vertices + 1, n_vertices + 2)
+    n_vertices += 3
+    text += "vertex 0.5 0.5 0.5\nvertex 0.500001 0.5 0.5\nvertex 0.5 0.500001 0.5\ntri %d %d %d\n" % (n_vertices, n_vertices + 1, n_vertices + 2)
+    fi = gpu.FileInfo(write(tmp_path, "many_lights", text))
+    assert fi.scene_desc.n_point_lights == 40 and fi.scene_desc.n_triangles == 704
+    cam = fi.camera()
+    scene = gpu.Scene(fi.scene_desc)
+    o = checkers.cpu_render(oracle, "rto_", fi.scene_desc, cam, fi.params(), want_ids=True)
+    assert o["stats"].shadow_rays == 41 * o["stats"].hits and 0 < o["stats"].shadow_blocked < o["stats"].shadow_rays
+    modes = dict(MODES, brute_force=abi.RT_FLAG_NO_FILTER, brute_force_as_written=abi.RT_FLAG_NO_FILTER | abi.RT_FLAG_PLAIN_TEST)
+    for mode, flags in modes.items():
+        g = scene.render(cam, fi.params(flags=flags), want_ids=True)
+        assert np.array_equal(g["ids"], o["ids"]), mode
+        assert np.array_equal(g["rgb"], o["rgb"]), mode
+        for f in ("samples", "culled", "closest_rays", "hits", "shadow_rays", "shadow_blocked"):
+            assert getattr(g["stats"], f) == getattr(o["stats"], f), (mode, f)
+    scene.close()
