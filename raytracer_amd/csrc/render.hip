@@ -1437,8 +1437,9 @@ DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, con
         // 12-byte and strided reads, which take the LDS twice as long), where its stage begins: the position in the tile
         // is made opaque before the head and the tail, so that their reads cannot be moved ahead of the branch before
         // them, and a step that ends at the front costs the LDS one read (two for rays of any origin).  (Reading the
-        // front's parts a step ahead, two triangles per turn of the loop with registers of their own, was measured: the
-        // compiler then waits for every outstanding read at the top of a step, the one just issued included: -1 %.)
+        // front's parts a step ahead, two triangles per turn of the loop with registers of their own, was measured, with
+        // the read issued at the end of the step before and at its start: -1 % either way.  The front's wait for the LDS
+        // is covered by the other waves of the SIMD.)
         struct FrontParts { float4 r0, r1; };
         const auto front_parts = [&](uint32_t k) __attribute__((always_inline)) {
             FrontParts f;
