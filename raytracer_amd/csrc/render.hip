@@ -336,7 +336,7 @@ DEV TriFront tri_front(V3 o, V3 d, float4 t0, float4 t1, float4 t2, Mask& out) {
     return f;
 }
 // The same for rays that all start at one point (rays from the eye): (a-o).n is then a property of
-// the triangle, computed once per tile by tile_shared_numerators with the very expression above.
+// the triangle, computed once per tile by stage_triangle_tile with the very expression above.
 // Triangles behind such rays are rare, so the sign test is left to tri_head's t < tolerance.
 DEV TriFront tri_front_shared(V3 d, float4 t0, float4 t1, float4 t2, float num, Mask& out) {
     const V3 n{t0.w, t1.w, t2.w};
