@@ -117,7 +117,7 @@ def main():
         previous = kind
     print()
     for variant, slots in totals.items():
-        print("common path (front + head), %s: %d issue slots per pair -> at most %.0f %% of the FP32 peak at full issue rate, %.0f %% at the 0.70 measured" % (variant, slots, 2700.0 / slots, 0.70 * 2700.0 / slots))
+        print("common path (front + head), %s: %d issue slots per pair -> at most %.0f %% of the FP32 peak at full issue rate, %.0f %% at the measured 0.82 of the issue slots and 0.90 of the peak's clock" % (variant, slots, 2700.0 / slots, 0.82 * 0.90 * 2700.0 / slots))
     print("\nThe common path is front + head: every lane of the wave rejected after alpha.  A wave all of whose lanes are rejected by the front skips the head too;")
     print("the tail runs only for a wave with a lane still in play, the fall-back only for a wave with an unsure lane.  The PMC passes (profiles/r2*_profile.txt)")
     print("give the executed mean: SQ_INSTS_VALU per (wave, triangle) step.")
