@@ -1505,8 +1505,69 @@ DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, con
         }
     }
 }
+// Reflected rays for the brute-force closest-hit scan, ordered by direction.  The staged test skips a stage when no ray of
+// the wave needs it, and the rays a wave takes from the list in image order were reflected by different small triangles:
+// they point anywhere.  A copy of the list in the order of 512 direction bins (3 bits per component; within a bin in the
+// order the workgroups arrive, i.e. roughly image order, so origins stay close too) gives the scan waves whose rays
+// agree on which triangles lie behind them.  Only the scan reads the copy: results go to the rays' slots, and every
+// other kernel keeps the list in image order.  Three launches: count per bin, offsets, scatter.
+#ifndef RT_DIR_LEVELS
+#define RT_DIR_LEVELS 8
+#endif
+constexpr uint32_t DIR_BINS = 512;
+static_assert(RT_DIR_LEVELS * RT_DIR_LEVELS * RT_DIR_LEVELS <= DIR_BINS, "levels per component of a direction");
+static_assert(2 * DIR_BINS <= SCAN_THREADS, "counts and cursors live in State::scan_block between two compactions");
+DEV uint32_t direction_bin(V3 d) {
+    constexpr float LEVELS = RT_DIR_LEVELS;
+    const auto level = [](float v) { return static_cast<uint32_t>(fminf(fmaxf((v + 1.0f) * (0.5f * LEVELS), 0.0f), LEVELS - 1.0f)); };   // (a NaN lands in level 0)
+    return level(d.x) + RT_DIR_LEVELS * (level(d.y) + RT_DIR_LEVELS * level(d.z));
+}
+__global__ void __launch_bounds__(BLOCK) k_direction_count(State st, uint32_t bounce, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t lds_count[DIR_BINS];
+    for (uint32_t b = threadIdx.x; b < DIR_BINS; b += BLOCK) lds_count[b] = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < st.counts[bounce]) {
+        const uint32_t slot = st.list[bounce & 1u][i];
+        atomicAdd(&lds_count[direction_bin(V3{st.dx[slot], st.dy[slot], st.dz[slot]})], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < DIR_BINS; b += BLOCK) if (lds_count[b]) atomicAdd(&counts[b], lds_count[b]);
+}
+__global__ void __launch_bounds__(DIR_BINS) k_direction_offsets(const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors) {
+    __shared__ uint32_t sums[DIR_BINS];
+    const uint32_t mine = counts[threadIdx.x];
+    sums[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t step = 1; step < DIR_BINS; step <<= 1) {
+        const uint32_t add = threadIdx.x >= step ? sums[threadIdx.x - step] : 0u;
+        __syncthreads();
+        sums[threadIdx.x] += add;
+        __syncthreads();
+    }
+    cursors[threadIdx.x] = sums[threadIdx.x] - mine;
+}
+__global__ void __launch_bounds__(BLOCK) k_direction_scatter(State st, uint32_t bounce, uint32_t* __restrict__ cursors, uint32_t* __restrict__ out) {
+    __shared__ uint32_t lds_count[DIR_BINS], lds_first[DIR_BINS];
+    for (uint32_t b = threadIdx.x; b < DIR_BINS; b += BLOCK) lds_count[b] = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const bool valid = i < st.counts[bounce];
+    uint32_t slot = 0, bin = 0, place = 0;
+    if (valid) {
+        slot = st.list[bounce & 1u][i];
+        bin = direction_bin(V3{st.dx[slot], st.dy[slot], st.dz[slot]});
+        place = atomicAdd(&lds_count[bin], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < DIR_BINS; b += BLOCK) if (lds_count[b]) lds_first[b] = atomicAdd(&cursors[b], lds_count[b]);
+    __syncthreads();
+    if (valid) out[lds_first[bin] + place] = slot;
+}
+
+// `list`: the rays in the order the scan takes them (the list of the bounce, or its copy in the order of k_direction_scatter)
 template <int R, bool STAGED>
-__global__ void __launch_bounds__(BLOCK) k_closest_tri_brute(DevScene sc, State st, uint32_t bounce) {
+__global__ void __launch_bounds__(BLOCK) k_closest_tri_brute(DevScene sc, State st, uint32_t bounce, const uint32_t* __restrict__ list) {
     __shared__ float4 lds[TILE_PRIMS * 4];
     const uint32_t n_rays = st.counts[bounce];
     const uint32_t base = blockIdx.x * (BLOCK * R);
@@ -1514,7 +1575,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri_brute(DevScene sc, State 
     uint32_t slot[R];
     bool valid[R];
     V3 o[R], d[R];
-    load_rays<R>(st, st.list[bounce & 1u], base, n_rays, slot, valid, o, d);
+    load_rays<R>(st, list, base, n_rays, slot, valid, o, d);
     float best_t[R]; uint32_t best_k[R];
     bool tame = true;
 #pragma unroll
@@ -3053,6 +3114,10 @@ constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;   // brute-force scans over sphe
 #define RT_TRI_RAYS_PER_LANE 1
 #endif
 constexpr int TRI_RAYS_PER_LANE = RT_TRI_RAYS_PER_LANE;
+#ifndef RT_SORT_RAYS_MIN_TRIANGLES
+#define RT_SORT_RAYS_MIN_TRIANGLES 2048
+#endif
+constexpr uint32_t SORT_RAYS_MIN_TRIANGLES = RT_SORT_RAYS_MIN_TRIANGLES;   // brute-force scans of fewer triangles take reflected rays in list order
 // Rays per lane of the hierarchy scans.  A wave's life is a chain of dependent L2 round trips whose
 // length grows with its number of rays, and a launch ends with its slowest wave: one ray per lane
 // is best while the top level is short (scene7: 391 top nodes).  Walking a long top level once per
@@ -3427,8 +3492,21 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
             timed(timer, 0, on, [&] {
                 if (sc.n_tri) timed(timer, 2, on, [&] {
                     if (walk[0]) hierarchy_scan(0);
-                    else if (plain_test) hipLaunchKernelGGL((k_closest_tri_brute<TRI_RAYS_PER_LANE, false>), dim3(tri_scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b);
-                    else hipLaunchKernelGGL((k_closest_tri_brute<TRI_RAYS_PER_LANE, true>), dim3(tri_scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b);
+                    else if (plain_test) hipLaunchKernelGGL((k_closest_tri_brute<TRI_RAYS_PER_LANE, false>), dim3(tri_scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b, static_cast<const uint32_t*>(sb.list[b & 1u]));
+                    else {
+                        // reflected rays of a long scan are taken in the order of their directions (launches follow each other on one stream in this mode;
+                        // the other list buffer is free until this bounce's compaction, the scan words between two compactions)
+                        const uint32_t* list = sb.list[b & 1u];
+                        if (!filter && b >= 1 && sc.n_tri >= SORT_RAYS_MIN_TRIANGLES) {
+                            uint32_t* counts = sb.scan_block, *cursors = sb.scan_block + DIR_BINS;
+                            (void)hipMemsetAsync(counts, 0, DIR_BINS * sizeof(uint32_t), on);
+                            hipLaunchKernelGGL(k_direction_count, dim3(ray_blocks()), dim3(BLOCK), 0, on, sb, b, counts);
+                            hipLaunchKernelGGL(k_direction_offsets, dim3(1), dim3(DIR_BINS), 0, on, static_cast<const uint32_t*>(counts), cursors);
+                            hipLaunchKernelGGL(k_direction_scatter, dim3(ray_blocks()), dim3(BLOCK), 0, on, sb, b, cursors, sb.list[(b + 1) & 1u]);
+                            list = sb.list[(b + 1) & 1u];
+                        }
+                        hipLaunchKernelGGL((k_closest_tri_brute<TRI_RAYS_PER_LANE, true>), dim3(tri_scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b, list);
+                    }
                 });
                 if (sc.n_sph) timed(timer, 3, on, [&] {
                     if (!walk[2]) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b);
