@@ -1510,7 +1510,7 @@ DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, con
 // they point anywhere.  A copy of the list in the order of 512 direction bins (3 bits per component; within a bin in the
 // order the workgroups arrive, i.e. roughly image order, so origins stay close too) gives the scan waves whose rays
 // agree on which triangles lie behind them.  Only the scan reads the copy: results go to the rays' slots, and every
-// other kernel keeps the list in image order.  Three launches: count per bin, offsets, scatter.
+// other kernel keeps the list in image order.  Three launches: count per bin, offsets, scatter (k_bin_*).
 #ifndef RT_DIR_LEVELS
 #define RT_DIR_LEVELS 8
 #endif
@@ -1522,19 +1522,28 @@ DEV uint32_t direction_bin(V3 d) {
     const auto level = [](float v) { return static_cast<uint32_t>(fminf(fmaxf((v + 1.0f) * (0.5f * LEVELS), 0.0f), LEVELS - 1.0f)); };   // (a NaN lands in level 0)
     return level(d.x) + RT_DIR_LEVELS * (level(d.y) + RT_DIR_LEVELS * level(d.z));
 }
-__global__ void __launch_bounds__(BLOCK) k_direction_count(State st, uint32_t bounce, uint32_t* __restrict__ counts) {
+// The same for the hit points the shadow rays start at, by the cell of an 8 x 8 x 8 grid over the scene box: neighbours in
+// image order lie at any depth of a scene of small triangles, and what is behind a shadow ray depends on where it starts.
+DEV uint32_t origin_bin(V3 p, const float* bb) {
+    const auto level = [](float v, float lo, float hi) { return static_cast<uint32_t>(fminf(fmaxf((v - lo) / (hi - lo) * 8.0f, 0.0f), 7.0f)); };   // (a NaN lands in level 0)
+    return level(p.x, bb[0], bb[3]) | (level(p.y, bb[1], bb[4]) << 3) | (level(p.z, bb[2], bb[5]) << 6);
+}
+// KEY 0: the rays of `bounce` by direction; KEY 1: the hit points of `bounce` (the list of bounce + 1) by cell
+template <int KEY>
+DEV uint32_t ray_bin(const DevScene& sc, const State& st, uint32_t slot) {
+    return KEY == 0 ? direction_bin(V3{st.dx[slot], st.dy[slot], st.dz[slot]}) : origin_bin(V3{st.px[slot], st.py[slot], st.pz[slot]}, sc.bb);
+}
+template <int KEY>
+__global__ void __launch_bounds__(BLOCK) k_bin_count(DevScene sc, State st, uint32_t bounce, uint32_t* __restrict__ counts) {
     __shared__ uint32_t lds_count[DIR_BINS];
     for (uint32_t b = threadIdx.x; b < DIR_BINS; b += BLOCK) lds_count[b] = 0u;
     __syncthreads();
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < st.counts[bounce]) {
-        const uint32_t slot = st.list[bounce & 1u][i];
-        atomicAdd(&lds_count[direction_bin(V3{st.dx[slot], st.dy[slot], st.dz[slot]})], 1u);
-    }
+    if (i < st.counts[bounce + KEY]) atomicAdd(&lds_count[ray_bin<KEY>(sc, st, st.list[(bounce + KEY) & 1u][i])], 1u);
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < DIR_BINS; b += BLOCK) if (lds_count[b]) atomicAdd(&counts[b], lds_count[b]);
 }
-__global__ void __launch_bounds__(DIR_BINS) k_direction_offsets(const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors) {
+__global__ void __launch_bounds__(DIR_BINS) k_bin_offsets(const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors) {
     __shared__ uint32_t sums[DIR_BINS];
     const uint32_t mine = counts[threadIdx.x];
     sums[threadIdx.x] = mine;
@@ -1547,16 +1556,17 @@ __global__ void __launch_bounds__(DIR_BINS) k_direction_offsets(const uint32_t* 
     }
     cursors[threadIdx.x] = sums[threadIdx.x] - mine;
 }
-__global__ void __launch_bounds__(BLOCK) k_direction_scatter(State st, uint32_t bounce, uint32_t* __restrict__ cursors, uint32_t* __restrict__ out) {
+template <int KEY>
+__global__ void __launch_bounds__(BLOCK) k_bin_scatter(DevScene sc, State st, uint32_t bounce, uint32_t* __restrict__ cursors, uint32_t* __restrict__ out) {
     __shared__ uint32_t lds_count[DIR_BINS], lds_first[DIR_BINS];
     for (uint32_t b = threadIdx.x; b < DIR_BINS; b += BLOCK) lds_count[b] = 0u;
     __syncthreads();
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    const bool valid = i < st.counts[bounce];
+    const bool valid = i < st.counts[bounce + KEY];
     uint32_t slot = 0, bin = 0, place = 0;
     if (valid) {
-        slot = st.list[bounce & 1u][i];
-        bin = direction_bin(V3{st.dx[slot], st.dy[slot], st.dz[slot]});
+        slot = st.list[(bounce + KEY) & 1u][i];
+        bin = ray_bin<KEY>(sc, st, slot);
         place = atomicAdd(&lds_count[bin], 1u);
     }
     __syncthreads();
@@ -1565,7 +1575,7 @@ __global__ void __launch_bounds__(BLOCK) k_direction_scatter(State st, uint32_t 
     if (valid) out[lds_first[bin] + place] = slot;
 }
 
-// `list`: the rays in the order the scan takes them (the list of the bounce, or its copy in the order of k_direction_scatter)
+// `list`: the rays in the order the scan takes them (the list of the bounce, or its copy in the order of k_bin_scatter)
 template <int R, bool STAGED>
 __global__ void __launch_bounds__(BLOCK) k_closest_tri_brute(DevScene sc, State st, uint32_t bounce, const uint32_t* __restrict__ list) {
     __shared__ float4 lds[TILE_PRIMS * 4];
@@ -2291,7 +2301,7 @@ DEV ShadowRay make_shadow_ray(const State& st, uint32_t slot, bool point, V3 lv)
 #endif
 constexpr uint32_t SHADOW_COMPACT_TILES = RT_SHADOW_COMPACT_TILES, SHADOW_RANGE_BLOCKS = RT_SHADOW_RANGE_BLOCKS, SHADOW_MIN_RANGES = RT_SHADOW_MIN_RANGES;
 template <bool STAGED>
-__global__ void __launch_bounds__(BLOCK) RT_SHADOW_BRUTE_ATTR k_shadow_tri_brute(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
+__global__ void __launch_bounds__(BLOCK) RT_SHADOW_BRUTE_ATTR k_shadow_tri_brute(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first, const uint32_t* __restrict__ list_in) {
     __shared__ float4 lds[TILE_PRIMS * 4];
     // Rays change lanes through the tile's memory, between two tiles: (o, limit) (d, tiles left) and the slot of the
     // rays the workgroup holds, by lane.  (Memory of their own would leave six workgroups per CU instead of nine.)
@@ -2305,7 +2315,6 @@ __global__ void __launch_bounds__(BLOCK) RT_SHADOW_BRUTE_ATTR k_shadow_tri_brute
     if (static_cast<unsigned long long>(blockIdx.x) * blocks_per_wg >= n_blocks) return;      // (also: no rays)
     uint32_t range_next = blockIdx.x * blocks_per_wg * BLOCK;                                 // the next ray of the range
     const uint32_t range_end = static_cast<uint32_t>(min(static_cast<unsigned long long>(n_rays), static_cast<unsigned long long>(range_next) + static_cast<unsigned long long>(blocks_per_wg) * BLOCK));
-    const uint32_t* __restrict__ list_in = st.list[(bounce + 1) & 1u];
     const float* __restrict__ L = sc.lights + (first_light + blockIdx.y) * 8;
     const bool point = L[0] != 0.0f;
     const V3 lv{L[1], L[2], L[3]};
@@ -3117,6 +3126,9 @@ constexpr int TRI_RAYS_PER_LANE = RT_TRI_RAYS_PER_LANE;
 #ifndef RT_SORT_RAYS_MIN_TRIANGLES
 #define RT_SORT_RAYS_MIN_TRIANGLES 2048
 #endif
+#ifndef RT_SORT_SHADOW_ORIGINS
+#define RT_SORT_SHADOW_ORIGINS 1
+#endif
 constexpr uint32_t SORT_RAYS_MIN_TRIANGLES = RT_SORT_RAYS_MIN_TRIANGLES;   // brute-force scans of fewer triangles take reflected rays in list order
 // Rays per lane of the hierarchy scans.  A wave's life is a chain of dependent L2 round trips whose
 // length grows with its number of rays, and a launch ends with its slowest wave: one ray per lane
@@ -3500,9 +3512,9 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                         if (!filter && b >= 1 && sc.n_tri >= SORT_RAYS_MIN_TRIANGLES) {
                             uint32_t* counts = sb.scan_block, *cursors = sb.scan_block + DIR_BINS;
                             (void)hipMemsetAsync(counts, 0, DIR_BINS * sizeof(uint32_t), on);
-                            hipLaunchKernelGGL(k_direction_count, dim3(ray_blocks()), dim3(BLOCK), 0, on, sb, b, counts);
-                            hipLaunchKernelGGL(k_direction_offsets, dim3(1), dim3(DIR_BINS), 0, on, static_cast<const uint32_t*>(counts), cursors);
-                            hipLaunchKernelGGL(k_direction_scatter, dim3(ray_blocks()), dim3(BLOCK), 0, on, sb, b, cursors, sb.list[(b + 1) & 1u]);
+                            hipLaunchKernelGGL(k_bin_count<0>, dim3(ray_blocks()), dim3(BLOCK), 0, on, sc, sb, b, counts);
+                            hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(DIR_BINS), 0, on, static_cast<const uint32_t*>(counts), cursors);
+                            hipLaunchKernelGGL(k_bin_scatter<0>, dim3(ray_blocks()), dim3(BLOCK), 0, on, sc, sb, b, cursors, sb.list[(b + 1) & 1u]);
                             list = sb.list[(b + 1) & 1u];
                         }
                         hipLaunchKernelGGL((k_closest_tri_brute<TRI_RAYS_PER_LANE, true>), dim3(tri_scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b, list);
@@ -3550,6 +3562,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                 closest_scans(b + 1, lane.side_stream);
                 HIP_TRY(hipEventRecord(joined, lane.side_stream));
             }
+            bool hits_in_cell_order = false;     // this bounce's hit points have been copied in the order of their cells
             if (sc.n_lights == 0) {
                 hipLaunchKernelGGL(k_shade, dim3(ray_blocks()), dim3(BLOCK), 0, stream, sc, sb, b, 0u, 0u, 1u);
             } else {
@@ -3561,8 +3574,23 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                     // brute-force shadow scan of one kind toward lights first.. (n of them)
                     auto brute_force = [&](int prim, uint32_t n, uint32_t first_light) {
                         const dim3 grid(prim == 0 ? ray_blocks() : scan_blocks(), n);    // the triangle scan takes one ray per lane (and cuts the list into ranges of its own: a workgroup beyond the last range returns)
-                        if (prim == 0 && plain_test) hipLaunchKernelGGL((k_shadow_tri_brute<false>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
-                        else if (prim == 0) hipLaunchKernelGGL((k_shadow_tri_brute<true>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
+                        if (prim == 0 && plain_test) hipLaunchKernelGGL((k_shadow_tri_brute<false>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0, static_cast<const uint32_t*>(sb.list[(b + 1) & 1u]));
+                        else if (prim == 0) {
+                            // a long scan takes the hit points in the order of their cells (the list buffer of this bounce's rays is free after its compaction)
+                            const uint32_t* list = sb.list[(b + 1) & 1u];
+                            if (RT_SORT_SHADOW_ORIGINS && !filter && sc.n_tri >= SORT_RAYS_MIN_TRIANGLES) {
+                                if (!hits_in_cell_order) {
+                                    uint32_t* counts = sb.scan_block, *cursors = sb.scan_block + DIR_BINS;
+                                    (void)hipMemsetAsync(counts, 0, DIR_BINS * sizeof(uint32_t), stream);
+                                    hipLaunchKernelGGL(k_bin_count<1>, dim3(ray_blocks()), dim3(BLOCK), 0, stream, sc, sb, b, counts);
+                                    hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(DIR_BINS), 0, stream, static_cast<const uint32_t*>(counts), cursors);
+                                    hipLaunchKernelGGL(k_bin_scatter<1>, dim3(ray_blocks()), dim3(BLOCK), 0, stream, sc, sb, b, cursors, sb.list[b & 1u]);
+                                    hits_in_cell_order = true;
+                                }
+                                list = sb.list[b & 1u];
+                            }
+                            hipLaunchKernelGGL((k_shadow_tri_brute<true>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0, list);
+                        }
                         else if (prim == 1) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                         else hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                     };
