@@ -267,7 +267,7 @@ int rt_write_png_end(void);
 /* ---- test hook -----------------------------------------------------------------
  * Evaluates ONE device routine of the render loop on n items, so that the GPU forms of the
  * reference's scalar and AVX routines can be compared bit for bit with known answers
- * (maths.cpp:9-159 fp_pow / fp_min / fp_max; ray_tracing.cpp:460-473, :265-297, :129-165, :169-206).
+ * (maths.cpp:9-159 fp_pow / fp_min / fp_max; ray_tracing.cpp:460-473, :265-297, :129-165, :169-206, :105-126, :208-263, :336-344, :555-579).
  * All pointers are host memory.  Layout per operation (floats):
  *   FP_POW, FP_MIN, FP_MAX, DIVIDE, DIVIDE_IN_RANGE: a[n], b[n] -> out[n]
  *   PRIMARY_RAY: a = eye, basis i, j, k, half_world w h, half width and half height in pixels (16);
@@ -276,7 +276,19 @@ int rt_write_png_end(void);
  *   TRIANGLE, TRIANGLE_STAGED: a = a, a_to_b, a_to_c per item (9); b = origin, direction per item -> out[n]
  *                (distance or FLT_MAX; STAGED evaluates the staged form the brute-force scans use and reports
  *                NaN where that form declares itself unsure and the scans fall back to the plain form)
- *   SPHERE:      a = centre, radius per item (4); b = origin, direction per item -> out[n] */
+ *   SPHERE:      a = centre, radius per item (4); b = origin, direction per item -> out[n]
+ *   ELLIPSOID, ELLIPSOID_STAGED: a = rows of the inverse transform, rows of the transform per item (24); b = origin, direction
+ *                per item -> distance or FLT_MAX (closest-hit body, ray_tracing.cpp:555-579); STAGED evaluates the form the
+ *                brute-force scans use and returns 2 floats per item: the result (FLT_MAX where a stage decided that the pair
+ *                cannot produce a distance below FLT_MAX) and the stage that decided (0, 1, 2; 3 = the test as written,
+ *                for records and rays outside the staged form's range)
+ *   ELLIPSOID_SHADOW, ELLIPSOID_SHADOW_STAGED: a = rows of the inverse transform (12), light position (3), 1 for a point
+ *                light / 0 for a directional one, per item; b = origin, direction per item -> 1 if the ellipsoid blocks the ray
+ *                (ray_tracing.cpp:376-401, :432-454), else 0; STAGED returns (result, stage) as above
+ *   ELLIPSOID_PARTS: a = rows of the inverse transform per item (12); b = origin, direction per item -> 8 floats per item:
+ *                origin in ellipsoid space (Mat3x4AVX * Vec3AVX, ray_tracing.cpp:105-126), direction in ellipsoid space
+ *                (transform_direction, :208-227), ellipsoid_is_absent as 1 / 0 (:336-344), intersect_with_unit_sphere of
+ *                that origin and the normalised direction (:229-263) */
 #define RT_DEBUG_FP_POW 0
 #define RT_DEBUG_FP_MIN 1
 #define RT_DEBUG_FP_MAX 2
@@ -287,6 +299,11 @@ int rt_write_png_end(void);
 #define RT_DEBUG_TRIANGLE 7
 #define RT_DEBUG_TRIANGLE_STAGED 8
 #define RT_DEBUG_SPHERE 9
+#define RT_DEBUG_ELLIPSOID 10
+#define RT_DEBUG_ELLIPSOID_STAGED 11
+#define RT_DEBUG_ELLIPSOID_SHADOW 12
+#define RT_DEBUG_ELLIPSOID_SHADOW_STAGED 13
+#define RT_DEBUG_ELLIPSOID_PARTS 14
 int rt_debug_eval(int op, uint32_t n, const float* a, const float* b, float* out);
 
 #ifdef __cplusplus

@@ -181,6 +181,62 @@ void ref_intersect_sphere8(const float o[3], const float d[3], const float* sph8
     Sphere8 s; std::memcpy(&s, sph8, sizeof s);
     _mm256_storeu_ps(out, intersect(load(Vector{o[0], o[1], o[2]}), load(Vector{d[0], d[1], d[2]}), s));
 }
+// The ellipsoid routines on one batch of 8 (inv8, fwd8: Mat3x4x8, 96 floats each): the reference's own operators and
+// functions (Mat3x4AVX * Vec3AVX, transform_direction, ellipsoid_is_absent, magnitude, intersect_with_unit_sphere), called
+// in the order of the closest-hit body, Source/ray_tracing.cpp:556-579 (that body is inline in intersect(Ray, Scene, int)
+// and cannot be called on its own).  Outputs per lane: o2, d2 as x[8] y[8] z[8]; absent as 1 / 0; the unit-sphere
+// distance; the final distance (FLT_MAX where absent).
+void ref_ellipsoid8(const float o[3], const float d[3], const float* inv8, const float* fwd8, float* o2, float* d2, float* absent, float* t2, float* dist) {
+    Mat3x4x8 inverse, forward;
+    std::memcpy(&inverse, inv8, sizeof inverse);
+    std::memcpy(&forward, fwd8, sizeof forward);
+    const Vec3AVX ray_start = load(Vector{o[0], o[1], o[2]});
+    const Vec3AVX ray_direction = load(Vector{d[0], d[1], d[2]});
+    const Mat3x4AVX ellipsoid_inverse_transform = load(inverse);
+    const Mat3x4AVX ellipsoid_transform = load(forward);
+    const Vec3AVX transformed_ray_start = ellipsoid_inverse_transform * ray_start;
+    Vec3AVX transformed_ray_direction = transform_direction(ellipsoid_inverse_transform, ray_direction);
+    _mm256_storeu_ps(o2, transformed_ray_start.x); _mm256_storeu_ps(o2 + 8, transformed_ray_start.y); _mm256_storeu_ps(o2 + 16, transformed_ray_start.z);
+    _mm256_storeu_ps(d2, transformed_ray_direction.x); _mm256_storeu_ps(d2 + 8, transformed_ray_direction.y); _mm256_storeu_ps(d2 + 16, transformed_ray_direction.z);
+    const __m256 ellipsoid_absent = ellipsoid_is_absent(transformed_ray_direction);
+    _mm256_storeu_ps(absent, _mm256_and_ps(ellipsoid_absent, _mm256_set1_ps(1.0f)));
+    const __m256 transformed_ray_direction_magnitude = magnitude(transformed_ray_direction);
+    const __m256 inverse_transformed_ray_direction_magnitude = _mm256_div_ps(_mm256_set1_ps(1.0f), transformed_ray_direction_magnitude);
+    transformed_ray_direction = inverse_transformed_ray_direction_magnitude * transformed_ray_direction;
+    const __m256 transformed_intersection_distances = intersect_with_unit_sphere(transformed_ray_start, transformed_ray_direction);
+    _mm256_storeu_ps(t2, transformed_intersection_distances);
+    const Vec3AVX transformed_intersection_point = transformed_ray_start + transformed_intersection_distances * transformed_ray_direction;
+    const Vec3AVX intersection_point = ellipsoid_transform * transformed_intersection_point;
+    const __m256 all_intersection_distances = magnitude(intersection_point - ray_start);
+    const __m256 infinity = _mm256_set1_ps(FLT_MAX);
+    _mm256_storeu_ps(dist, _mm256_or_ps(_mm256_andnot_ps(ellipsoid_absent, all_intersection_distances), _mm256_and_ps(ellipsoid_absent, infinity)));
+}
+// path_is_blocked itself (Source/ray_tracing.cpp:347-458) on a scene that holds this one batch of ellipsoids and nothing else.
+// point != 0: light[3] is a position; the direction the function derives (:350-354) is returned in dir_out.
+// point == 0: light[3] is the directional light's direction; dir_out = -1 * light (:411).
+int ref_ellipsoid8_blocks(const float start[3], const float light[3], int point, const float* inv8, float dir_out[3]) {
+    Scene s;
+    s.ellipsoid8_inverse_transforms.resize(1);
+    s.ellipsoid8_transforms.resize(1);
+    std::memcpy(&s.ellipsoid8_inverse_transforms[0], inv8, sizeof(Mat3x4x8));
+    std::memset(&s.ellipsoid8_transforms[0], 0, sizeof(Mat3x4x8));
+    const Vector from{start[0], start[1], start[2]};
+    if (point) {
+        const PointLightSource l{Vector{light[0], light[1], light[2]}, Colour{1.0f, 1.0f, 1.0f}};
+        const Vector start_to_light = l.position - from;
+        float lanes[8];
+        const __m256 inverse_distance_to_light = _mm256_div_ps(_mm256_set1_ps(1.0f), _mm256_set1_ps(magnitude(start_to_light)));
+        const Vec3AVX ray_direction = inverse_distance_to_light * load(start_to_light);
+        _mm256_storeu_ps(lanes, ray_direction.x); dir_out[0] = lanes[0];
+        _mm256_storeu_ps(lanes, ray_direction.y); dir_out[1] = lanes[0];
+        _mm256_storeu_ps(lanes, ray_direction.z); dir_out[2] = lanes[0];
+        return path_is_blocked(from, l, s) ? 1 : 0;
+    }
+    const DirectionalLightSource l{Vector{light[0], light[1], light[2]}, Colour{1.0f, 1.0f, 1.0f}};
+    const Vector direction = -1.0f * l.direction;
+    dir_out[0] = direction.x; dir_out[1] = direction.y; dir_out[2] = direction.z;
+    return path_is_blocked(from, l, s) ? 1 : 0;
+}
 // full trace of one ray
 void ref_trace(const rt_scene_desc* desc, const float o[3], const float d[3], int depth, float out[3]) {
     const Scene s = scene_from_desc(*desc);

@@ -446,6 +446,49 @@ void rto_intersect_triangle8(const float o[3], const float d[3], const float* t8
 void rto_intersect_sphere8(const float o[3], const float d[3], const float* s8, float out[8]) {
     for (int j = 0; j < 8; ++j) out[j] = hit_sphere(V3{o[0], o[1], o[2]}, V3{d[0], d[1], d[2]}, V3{s8[j], s8[8 + j], s8[16 + j]}, s8[24 + j]);
 }
+// The ellipsoid routines on one batch of 8, same contract as ref_ellipsoid8 in ref_harness.cpp (ray_tracing.cpp:556-579).
+void rto_ellipsoid8(const float o[3], const float d[3], const float* inv8, const float* fwd8, float* o2_out, float* d2_out, float* absent_out, float* t2_out, float* dist_out) {
+    const V3 ro{o[0], o[1], o[2]}, rd{d[0], d[1], d[2]};
+    for (int j = 0; j < 8; ++j) {
+        const M34 minv = load_mat(inv8, j);
+        const M34 m = load_mat(fwd8, j);
+        const V3 o2 = vmat_point(minv, ro);
+        V3 d2 = vmat_dir(minv, rd);
+        o2_out[j] = o2.x; o2_out[8 + j] = o2.y; o2_out[16 + j] = o2.z;
+        d2_out[j] = d2.x; d2_out[8 + j] = d2.y; d2_out[16 + j] = d2.z;
+        const bool absent = ellipsoid_absent(d2);
+        absent_out[j] = absent ? 1.0f : 0.0f;
+        const float inv_mag = 1.0f / sqrtf(vdot(d2, d2));
+        d2 = scale(inv_mag, d2);
+        const float t2 = hit_unit_sphere(o2, d2);
+        t2_out[j] = t2;
+        const V3 p2 = add(o2, scale(t2, d2));
+        const V3 p = vmat_point(m, p2);
+        const V3 op = sub(p, ro);
+        const float dist = sqrtf(vdot(op, op));
+        dist_out[j] = absent ? FLT_MAX : dist;
+    }
+}
+// path_is_blocked on a scene that holds one batch of ellipsoids and nothing else, same contract as ref_ellipsoid8_blocks.
+int rto_ellipsoid8_blocks(const float start[3], const float light[3], int point, const float* inv8, float dir_out[3]) {
+    rt_scene_desc desc;
+    std::memset(&desc, 0, sizeof desc);
+    desc.ellipsoid8_inverse_transforms = inv8;
+    desc.n_ellipsoid8 = 1;
+    const V3 from{start[0], start[1], start[2]};
+    V3 dir;
+    if (point) {
+        const V3 to_light = sub(V3{light[0], light[1], light[2]}, from);
+        dir = scale(1.0f / smagnitude(to_light), to_light);
+    } else {
+        desc.directional_light[0] = light[0]; desc.directional_light[1] = light[1]; desc.directional_light[2] = light[2];
+        desc.has_directional_light = 1;
+        dir = scale(-1.0f, V3{light[0], light[1], light[2]});
+    }
+    dir_out[0] = dir.x; dir_out[1] = dir.y; dir_out[2] = dir.z;
+    Counters cn;
+    return path_is_blocked(SceneView{&desc}, from, point ? light : nullptr, cn) ? 1 : 0;
+}
 void rto_trace(const rt_scene_desc* desc, const float o[3], const float d[3], int depth, float out[3]) {
     Counters cn;
     trace(SceneView{desc}, V3{o[0], o[1], o[2]}, V3{d[0], d[1], d[2]}, depth, out, nullptr, cn);

@@ -223,11 +223,34 @@ def write_png_end():
     _check(lib().rt_write_png_end())
 
 
-def debug_eval(op, a, b, out_per_item, n=None):
-    """rt_debug_eval: one device routine on n items; a, b are float32 arrays laid out as include/rt_amd.h says."""
+# floats per item of `a`, fixed floats of `a`, floats per item of `b`, floats per item of the result (rt_debug_eval in include/rt_amd.h)
+_DEBUG_SHAPES = {
+    abi.RT_DEBUG_FP_POW: (1, 0, 1, 1), abi.RT_DEBUG_FP_MIN: (1, 0, 1, 1), abi.RT_DEBUG_FP_MAX: (1, 0, 1, 1), abi.RT_DEBUG_DIVIDE: (1, 0, 1, 1),
+    abi.RT_DEBUG_DIVIDE_IN_RANGE: (1, 0, 1, 1), abi.RT_DEBUG_PRIMARY_RAY: (0, 16, 4, 3), abi.RT_DEBUG_SCENE_BOX: (0, 6, 6, 2),
+    abi.RT_DEBUG_TRIANGLE: (9, 0, 6, 1), abi.RT_DEBUG_TRIANGLE_STAGED: (9, 0, 6, 1), abi.RT_DEBUG_SPHERE: (4, 0, 6, 1),
+    abi.RT_DEBUG_ELLIPSOID: (24, 0, 6, 1), abi.RT_DEBUG_ELLIPSOID_STAGED: (24, 0, 6, 2), abi.RT_DEBUG_ELLIPSOID_SHADOW: (16, 0, 6, 1),
+    abi.RT_DEBUG_ELLIPSOID_SHADOW_STAGED: (16, 0, 6, 2), abi.RT_DEBUG_ELLIPSOID_PARTS: (12, 0, 6, 8),
+}
+
+
+def debug_eval(op, a, b, out_per_item=None, n=None):
+    """rt_debug_eval: one device routine on n items; a, b are float32 arrays laid out as include/rt_amd.h says.
+
+    n defaults to the number of items `b` holds (its size over the operation's floats per item, whatever its shape); the sizes
+    of both arrays are checked against the operation's layout before the library reads them."""
     a = np.ascontiguousarray(a, np.float32)
     b = np.ascontiguousarray(b, np.float32)
-    n = len(b) if n is None else n
-    out = np.zeros(n * out_per_item, np.float32)
+    if int(op) not in _DEBUG_SHAPES:
+        raise ValueError("rt_debug_eval: unknown operation %r" % (op,))
+    a_item, a_fixed, b_item, out_item = _DEBUG_SHAPES[int(op)]
+    if out_per_item is not None and out_per_item != out_item:
+        raise ValueError("operation %d returns %d floats per item, not %d" % (op, out_item, out_per_item))
+    if n is None:
+        if b.size % b_item:
+            raise ValueError("b holds %d floats, not a multiple of %d per item" % (b.size, b_item))
+        n = b.size // b_item
+    if b.size < n * b_item or a.size < n * a_item + a_fixed:
+        raise ValueError("rt_debug_eval: %d items need %d floats in a and %d in b (got %d, %d)" % (n, n * a_item + a_fixed, n * b_item, a.size, b.size))
+    out = np.zeros(n * out_item, np.float32)
     _check(lib().rt_debug_eval(int(op), n, a.ctypes.data, b.ctypes.data, out.ctypes.data))
     return out

@@ -13,6 +13,7 @@
 #include <fstream>
 #include <stdexcept>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -504,28 +505,32 @@ struct PendingImage {
     std::string filename, error;
     int rc = 0;
     bool busy = false;
+    std::mutex guard;          // begin and end may be called from different threads
+    // an image begun and never ended is still written: the writer is joined when the library is unloaded
+    ~PendingImage() { if (worker.joinable()) worker.join(); }
 } g_pending_image;
 }
 int rt_write_png_begin(const char* filename, uint32_t width, uint32_t height, const uint8_t* rgb) {
     if (!filename || !rgb || !width || !height) return rt_fail(RT_ERR_ARGUMENT, "rt_write_png_begin: bad argument");
+    std::lock_guard<std::mutex> lock(g_pending_image.guard);
     if (g_pending_image.busy) return rt_fail(RT_ERR_ARGUMENT, "rt_write_png_begin: an image is still being written (rt_write_png_end)");
     try {
         g_pending_image.pixels.assign(rgb, rgb + static_cast<size_t>(width) * height * 3);
         g_pending_image.filename = filename;
-        g_pending_image.busy = true;
         g_pending_image.worker = std::thread([width, height] {
             g_pending_image.rc = rt_write_png(g_pending_image.filename.c_str(), width, height, g_pending_image.pixels.data());
             if (g_pending_image.rc) g_pending_image.error = rt_last_error();
         });
+        g_pending_image.busy = true;
     } catch (const std::exception& e) {
-        g_pending_image.busy = false;
         return rt_fail(RT_ERR_IO, e.what());
     }
     return 0;
 }
 int rt_write_png_end(void) {
+    std::lock_guard<std::mutex> lock(g_pending_image.guard);
     if (!g_pending_image.busy) return 0;
-    g_pending_image.worker.join();
+    if (g_pending_image.worker.joinable()) g_pending_image.worker.join();
     g_pending_image.busy = false;
     return g_pending_image.rc ? rt_fail(g_pending_image.rc, g_pending_image.error.c_str()) : 0;
 }

@@ -39,6 +39,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -111,6 +112,7 @@ struct DevScene {
     const float4* sph;   // (centre, radius)
     const float4* ell;   // 6 x float4: rows of the inverse transform, rows of the transform
     const float4* ell_light;  // [point light][ellipsoid]: inverse transform applied to the light position
+    const float* ell_ok;      // per ellipsoid: 1 if the staged form of the test is proven for the record (ell_record_is_regular), else 0
     const float* tri_mat;
     const float* sph_mat;
     const float* ell_mat;
@@ -669,10 +671,9 @@ DEV float sphere_roots(const SphereFront& f) {
 }
 DEV float hit_sphere(V3 o, V3 d, float4 s) { return sphere_roots(sphere_front(o, d, s)); }
 
-// ray_tracing.cpp:229-263
-DEV float hit_unit_sphere(V3 o, V3 d) {
+// ray_tracing.cpp:229-263; oo = o.o as :235 computes it
+DEV float unit_sphere_distance(V3 o, float oo, V3 d) {
     const float mid = vdot(scale(-1.0f, o), d);
-    const float oo = vdot(o, o);
     const float mid2 = mid * mid;
     const float perp2 = oo - mid2;
     const float disc = 1.0f - perp2;
@@ -686,6 +687,7 @@ DEV float hit_unit_sphere(V3 o, V3 d) {
     const float p1 = inv1 ? FLT_MAX : d1;
     return p0 < p1 ? p0 : p1;
 }
+DEV float hit_unit_sphere(V3 o, V3 d) { return unit_sphere_distance(o, vdot(o, o), d); }
 
 // closest-hit body for one ellipsoid, ray_tracing.cpp:555-579
 DEV float hit_ellipsoid(V3 o, V3 d, float4 i0, float4 i1, float4 i2, float4 m0, float4 m1, float4 m2) {
@@ -718,6 +720,134 @@ DEV bool ellipsoid_blocks(V3 o, V3 d, float4 i0, float4 i1, float4 i2, bool poin
     float t2 = hit_unit_sphere(o2, d2);
     t2 = absent ? FLT_MAX : t2;
     return t2 < limit;
+}
+
+
+// The ellipsoid tests in stages, for the brute-force scans.  As written (hit_ellipsoid, ellipsoid_blocks) a pair costs two
+// matrix products, two IEEE square roots and an IEEE division before anything is decided, and almost every ray misses
+// almost every ellipsoid.  The stages return what the test as written returns, bit for bit where it matters (see below),
+// and skip what the outcome does not depend on; a stage is skipped when no ray of the wave needs it.
+//   stage 0 (ell_parts, ell_certain_miss): O = M^-1 o, D = M^-1 d (not normalised), q = D.D and o'.o' = O.O exactly as the
+//            test computes them.  With u = D/|D| in real arithmetic the test's discriminant is, up to rounding,
+//            disc* = 1 - (O.O - (O.u)^2).  Its evaluated value differs from disc* by less than 23 eps (|O|^2 + 1)
+//            (eps = 2^-24): the normalised direction carries 4.5 eps (q 3 eps, square root, reciprocal and product one
+//            each), the mid point 8 eps |O|, its square 17.1 eps |O|^2, O.O 3 eps |O|^2, the two differences one eps of
+//            their results each.  So disc* < -K (|O|^2 + 1) with K = 32 eps makes the evaluated discriminant negative:
+//            the unit sphere is missed and the distance is FLT_MAX.  In terms of quantities that need no division,
+//                 q (|O|^2 (1 - K) - (1 + K)) > (O.D)^2,
+//            evaluated as  fma(O.O, 1 - K', -(1 + K')) * q  >  m * m,  m = O.D,  with K' = 2^-17 = 128 eps: the evaluation's
+//            own roundings (m^2: 7.1 eps |O|^2 q, the left side 8.5 eps |O|^2 q) are covered by K' - K = 96 eps.  A NaN
+//            anywhere makes the comparison false, which leaves the pair to the next stage.
+//   stage 1 (ell_root): the absent mask, the normalisation and the unit-sphere distance t' exactly as written.  A lane that
+//            is absent, or whose t' is not below FLT_MAX (a miss, or NaN), is out: as written its result is FLT_MAX
+//            (absent), or the world distance of the "point" o' + FLT_MAX d', which is never below FLT_MAX for a regular
+//            record (below), or NaN; none of them is below any closest distance so far nor below a light's distance.
+//   tail    (ell_world_distance): p' = o' + t' d', p = M p', |p - o| exactly as written, for every lane of a wave that has
+//            a lane with a root.
+// Range.  The argument needs finite intermediates, no underflow that matters, and a transform that takes the point at
+// FLT_MAX to an overflow: a record is REGULAR (ell_record_is_regular, in double, once per scene) if it is all zeros (a
+// padding lane: D = 0, absent either way), or if every entry is finite, |M^-1| entries <= 2^20, translations <= 2^30,
+// the singular values of both 3x3 parts lie within [2^-30, 2^20] resp. [2^-30, ...] and their condition numbers are at
+// most 2^14.  Rays must be tame (ray_is_tame: |o| <= 4096, |d| <= 2 per component) with |d|^2 >= 1/4.  Then |O| < 2^35,
+// q in [2^-63, 2^48], every product above is finite, and the left side of the stage-0 comparison can only be positive when
+// |O|^2 > 1, i.e. when q |O|^2 is far above the underflow range.  For a miss, |p'| >= 0.99 FLT_MAX, so some component of
+// M p' exceeds 0.98 sigma_min(M) FLT_MAX / sqrt(3) - |translation| > 1e29 in magnitude (rounding: 12 eps times the condition
+// number, below 2 %), its square overflows, and the distance is +inf or NaN.  A tile of the list that holds a record that
+// is not regular, and a wave that holds a ray that is not tame, go through the test as written.
+constexpr float ELL_MARGIN = 7.62939453125e-6f;        // K' = 2^-17
+DEV bool ray_is_tame_for_ellipsoids(V3 o, V3 d) { return ray_is_tame(o, d) && vdot(d, d) >= 0.25f; }
+struct EllParts { V3 O, D; float oo, q; };
+DEV float ell_margin_term(float oo) { return fma_(oo, 1.0f - ELL_MARGIN, -(1.0f + ELL_MARGIN)); }
+DEV EllParts ell_parts(float4 i0, float4 i1, float4 i2, V3 o, V3 d) {
+    EllParts e;
+    e.O = vmat_point(i0, i1, i2, o);
+    e.D = vmat_dir(i0, i1, i2, d);
+    e.oo = vdot(e.O, e.O);
+    e.q = vdot(e.D, e.D);
+    return e;
+}
+// the same for rays that all start at one point: O and O.O are then properties of the ellipsoid (stage_ellipsoid_tile)
+DEV EllParts ell_parts_shared(float4 i0, float4 i1, float4 i2, float oo, V3 d) {
+    EllParts e;
+    e.O = V3{i0.w, i1.w, i2.w};
+    e.D = vmat_dir(i0, i1, i2, d);
+    e.oo = oo;
+    e.q = vdot(e.D, e.D);
+    return e;
+}
+// `margin_term` = ell_margin_term(e.oo)
+DEV bool ell_certain_miss(const EllParts& e, float margin_term) {
+    const float m = vdot(e.O, e.D);
+    return margin_term * e.q > m * m;
+}
+struct EllRoot { V3 d2; float t2; bool absent; };
+DEV EllRoot ell_root(const EllParts& e) {
+    EllRoot r;
+    r.absent = (e.D.x < TOL) & (e.D.y < TOL) & (e.D.z < TOL);   // ray_tracing.cpp:336-344
+    const float inv_mag = 1.0f / sqrt_(e.q);
+    r.d2 = scale(inv_mag, e.D);
+    r.t2 = unit_sphere_distance(e.O, e.oo, r.d2);
+    return r;
+}
+DEV bool ell_root_is_out(const EllRoot& r) { return r.absent | !(r.t2 < FLT_MAX); }
+DEV float ell_world_distance(V3 o, const EllParts& e, const EllRoot& r, float4 m0, float4 m1, float4 m2) {
+    const V3 p2 = add(e.O, scale(r.t2, r.d2));
+    const V3 p = vmat_point(m0, m1, m2, p2);
+    const V3 op = sub(p, o);
+    const float dist = sqrt_(vdot(op, op));
+    return r.absent ? FLT_MAX : dist;
+}
+// shadow rays: the limit in ellipsoid space (ray_tracing.cpp:388-389) and the comparison (:392-397, :445-450)
+DEV bool ell_root_blocks(const EllParts& e, const EllRoot& r, bool point, V3 l2) {
+    float limit = FLT_MAX;
+    if (point) {
+        const V3 dl = sub(l2, e.O);
+        limit = sqrt_(vdot(dl, dl));
+    }
+    const float t2 = r.absent ? FLT_MAX : r.t2;
+    return t2 < limit;
+}
+constexpr float ELL_LIGHT_COORD = 1.152921504606847e18f;    // 2^60: a light farther than this in ellipsoid space makes its tile go as written
+
+// smallest and largest eigenvalue of a symmetric 3x3 matrix (trigonometric form; absolute error a few 1e-16 of the largest)
+__device__ void sym3_eig_range(double a00, double a01, double a02, double a11, double a12, double a22, double& lo, double& hi) {
+    const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+    const double q = (a00 + a11 + a22) / 3.0;
+    const double p2 = (a00 - q) * (a00 - q) + (a11 - q) * (a11 - q) + (a22 - q) * (a22 - q) + 2.0 * p1;
+    const double pp = sqrt(p2 / 6.0);
+    if (!(pp > 1.0e-300)) { lo = hi = q; return; }
+    const double b00 = (a00 - q) / pp, b11 = (a11 - q) / pp, b22 = (a22 - q) / pp, b01 = a01 / pp, b02 = a02 / pp, b12 = a12 / pp;
+    const double det = b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02);
+    const double phi = acos(fmax(-1.0, fmin(1.0, det / 2.0))) / 3.0;
+    hi = q + 2.0 * pp * cos(phi);
+    lo = q + 2.0 * pp * cos(phi + 2.0943951023931953);
+}
+// `rec`: the six rows of an ellipsoid record (inverse transform, transform)
+__device__ bool ell_record_is_regular(const float4* rec) {
+    bool finite = true, zero = true;
+    double a_max = 0.0, t_max = 0.0, f_max = 0.0, w_max = 0.0;
+    for (int row = 0; row < 3; ++row) {
+        const float4 i = rec[row], m = rec[3 + row];
+        finite = finite && isfinite(i.x) && isfinite(i.y) && isfinite(i.z) && isfinite(i.w) && isfinite(m.x) && isfinite(m.y) && isfinite(m.z) && isfinite(m.w);
+        zero = zero && i.x == 0.0f && i.y == 0.0f && i.z == 0.0f && i.w == 0.0f;
+        a_max = fmax(a_max, fmax(fabs(static_cast<double>(i.x)), fmax(fabs(static_cast<double>(i.y)), fabs(static_cast<double>(i.z)))));
+        f_max = fmax(f_max, fmax(fabs(static_cast<double>(m.x)), fmax(fabs(static_cast<double>(m.y)), fabs(static_cast<double>(m.z)))));
+        t_max = fmax(t_max, fabs(static_cast<double>(i.w)));
+        w_max = fmax(w_max, fabs(static_cast<double>(m.w)));
+    }
+    if (!finite) return false;
+    if (zero) return true;
+    constexpr double P20 = 1048576.0, P30 = 1073741824.0, PM60 = 8.673617379884035e-19, PM28 = 3.725290298461914e-9;
+    if (!(a_max <= P20 && t_max <= P30 && f_max <= P30 && w_max <= P30)) return false;
+    for (int part = 0; part < 2; ++part) {
+        const double M[3][3] = {{rec[3 * part].x, rec[3 * part].y, rec[3 * part].z}, {rec[3 * part + 1].x, rec[3 * part + 1].y, rec[3 * part + 1].z}, {rec[3 * part + 2].x, rec[3 * part + 2].y, rec[3 * part + 2].z}};
+        double g[3][3];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g[r][c] = M[0][r] * M[0][c] + M[1][r] * M[1][c] + M[2][r] * M[2][c];
+        double lo, hi;
+        sym3_eig_range(g[0][0], g[0][1], g[0][2], g[1][1], g[1][2], g[2][2], lo, hi);
+        if (!(lo >= PM60 && lo >= PM28 * hi && hi <= P20 * P20 * P20)) return false;
+    }
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -792,7 +922,7 @@ __global__ void __launch_bounds__(BLOCK) k_prep_spheres(const float* __restrict_
     out[k] = make_float4(p[0], p[8], p[16], p[24]);
 }
 
-__global__ void __launch_bounds__(BLOCK) k_prep_ellipsoids(const float* __restrict__ inv8, const float* __restrict__ fwd8, uint32_t nb, float4* __restrict__ out) {
+__global__ void __launch_bounds__(BLOCK) k_prep_ellipsoids(const float* __restrict__ inv8, const float* __restrict__ fwd8, uint32_t nb, float4* __restrict__ out, float* __restrict__ ok) {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= 8u * nb) return;
     const uint32_t j = k / nb, i = k % nb;
@@ -803,6 +933,7 @@ __global__ void __launch_bounds__(BLOCK) k_prep_ellipsoids(const float* __restri
         o[row] = make_float4(pi[(row * 4 + 0) * 8], pi[(row * 4 + 1) * 8], pi[(row * 4 + 2) * 8], pi[(row * 4 + 3) * 8]);
         o[3 + row] = make_float4(pf[(row * 4 + 0) * 8], pf[(row * 4 + 1) * 8], pf[(row * 4 + 2) * 8], pf[(row * 4 + 3) * 8]);
     }
+    ok[k] = ell_record_is_regular(o) ? 1.0f : 0.0f;
 }
 
 // Box records (box_keeps), built in double.  Leaves: a box that contains every hit point o + t d the
@@ -2100,6 +2231,193 @@ __global__ void __launch_bounds__(BLOCK) k_closest_ell(DevScene sc, State st, ui
     for (int r = 0; r < R; ++r) if (valid[r]) st.key_ell[slot[r]] = best_k[r] == 0xFFFFFFFFu ? NO_HIT_KEY : pack_hit(best_t[r], best_k[r]);
 }
 
+
+// True for every thread of the workgroup when all its rays start at one point (rays from the eye) and `fit` holds for all
+// of them; o_block is then that point.  Ends with a barrier.
+template <int R>
+DEV bool workgroup_shares_origin(const V3 (&o)[R], bool fit, V3& o_block) {
+    __shared__ float lds_origin[3];
+    bool same = true;
+#pragma unroll
+    for (int r = 0; r < R; ++r) same = same && o[r].x == o[0].x && o[r].y == o[0].y && o[r].z == o[0].z;
+    if (threadIdx.x == 0) { lds_origin[0] = o[0].x; lds_origin[1] = o[0].y; lds_origin[2] = o[0].z; }
+    __syncthreads();
+    o_block = V3{lds_origin[0], lds_origin[1], lds_origin[2]};
+    same = same && o[0].x == o_block.x && o[0].y == o_block.y && o[0].z == o_block.z;
+    return __syncthreads_and(same && fit) != 0;
+}
+
+// A tile of ellipsoid records for the staged scans, one ellipsoid per thread: four arrays of TILE_PRIMS float4,
+//   [row] (row of the inverse transform . xyz, X[row]),  row = 0, 1, 2
+// with X the translation column, or - when all rays of the workgroup start at `o` (`shared`: rays from the eye) - that
+// origin in ellipsoid space, M^-1 o, computed here with the expression of the test; and
+//   [3]   (O.O, ell_margin_term(O.O), -, -) for a shared origin; the light's position in ellipsoid space for shadow rays
+//         toward a point light (`light_row`: that light's row of DevScene::ell_light, else null).
+// A step that ends at stage 0 (ell_certain_miss) reads three (shadow rays, reflected rays) or four (rays from the eye)
+// 16-byte words; the rows of the transform itself, which only the tail needs, stay in memory.
+// Returns true if this thread's record, or the light's position in its space, is outside the range the staged form is proven for.
+DEV bool stage_ellipsoid_tile(float4* lds, const DevScene& sc, uint32_t first, uint32_t count, bool shared, V3 o, const float4* __restrict__ light_row) {
+    if (threadIdx.x >= count) return false;
+    const uint32_t k = first + threadIdx.x;
+    const float4* g = sc.ell + static_cast<size_t>(k) * 6;
+    float4 i0 = g[0], i1 = g[1], i2 = g[2];
+    bool irregular = sc.ell_ok[k] == 0.0f;
+    float4 extra = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (shared) {
+        const V3 O = vmat_point(i0, i1, i2, o);
+        const float oo = vdot(O, O);
+        i0.w = O.x; i1.w = O.y; i2.w = O.z;
+        extra = make_float4(oo, ell_margin_term(oo), 0.0f, 0.0f);
+    } else if (light_row) {
+        extra = light_row[k];
+        irregular = irregular || !(fmaxf(fabsf(extra.x), fmaxf(fabsf(extra.y), fabsf(extra.z))) <= ELL_LIGHT_COORD);
+    }
+    lds[threadIdx.x] = i0;
+    lds[TILE_PRIMS + threadIdx.x] = i1;
+    lds[2 * TILE_PRIMS + threadIdx.x] = i2;
+    lds[3 * TILE_PRIMS + threadIdx.x] = extra;
+    return irregular;
+}
+
+// Closest hit over one staged tile, R rays per lane.  Lanes past the end of the list repeat a ray of the list (load_rays),
+// so every lane's vote counts.
+template <int R, bool SHARED>
+DEV void ellipsoid_tile_closest(const float4* lds, const float4* __restrict__ records, uint32_t first, uint32_t count,
+                                const V3 (&o)[R], const V3 (&d)[R], float (&best_t)[R], uint32_t (&best_k)[R]) {
+    for (uint32_t k = 0; k < count; ++k) {
+        const float4 i0 = lds[k], i1 = lds[TILE_PRIMS + k], i2 = lds[2 * TILE_PRIMS + k];
+        EllParts e[R];
+        Mask open = 0;
+        if (SHARED) {
+            const float2 extra = *reinterpret_cast<const float2*>(lds + 3 * TILE_PRIMS + k);    // (O.O, margin term)
+#pragma unroll
+            for (int r = 0; r < R; ++r) { e[r] = ell_parts_shared(i0, i1, i2, extra.x, d[r]); open |= ballot(!ell_certain_miss(e[r], extra.y)); }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { e[r] = ell_parts(i0, i1, i2, o[r], d[r]); open |= ballot(!ell_certain_miss(e[r], ell_margin_term(e[r].oo))); }
+        }
+        if (open == 0) continue;
+        EllRoot root[R];
+        Mask in_play = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { root[r] = ell_root(e[r]); in_play |= ballot(!ell_root_is_out(root[r])); }
+        if (in_play == 0) continue;
+        const float4* m = records + static_cast<size_t>(first + k) * 6 + 3;
+        const float4 m0 = m[0], m1 = m[1], m2 = m[2];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float t = ell_world_distance(o[r], e[r], root[r], m0, m1, m2);
+            if (t < best_t[r]) { best_t[r] = t; best_k[r] = first + k; }
+        }
+    }
+}
+
+// Brute force over the ellipsoid list (RT_FLAG_NO_FILTER, and lists too short for a hierarchy) with the test in stages
+// (ell_parts ...); k_closest_ell above is the same scan with the test as written (RT_FLAG_PLAIN_TEST).
+template <int R>
+__global__ void __launch_bounds__(BLOCK) k_closest_ell_staged(DevScene sc, State st, uint32_t bounce) {
+    __shared__ float4 lds[TILE_PRIMS * 4];
+    const uint32_t n_rays = st.counts[bounce];
+    const uint32_t base = blockIdx.x * (BLOCK * R);
+    if (base >= n_rays) return;
+    uint32_t slot[R];
+    bool valid[R];
+    V3 o[R], d[R];
+    load_rays<R>(st, st.list[bounce & 1u], base, n_rays, slot, valid, o, d);
+    float best_t[R]; uint32_t best_k[R];
+    bool tame = true;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { best_t[r] = FLT_MAX; best_k[r] = 0xFFFFFFFFu; tame = tame && ray_is_tame_for_ellipsoids(o[r], d[r]); }
+    const bool staged_wave = __all(tame);
+    V3 o_block;
+    const bool shared_origin = workgroup_shares_origin<R>(o, tame, o_block);
+    for (uint32_t first = 0; first < sc.n_ell; first += TILE_PRIMS) {
+        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_ell - first);
+        __syncthreads();
+        const bool as_written = __syncthreads_or(stage_ellipsoid_tile(lds, sc, first, count, shared_origin, o_block, nullptr));
+        if (as_written || !staged_wave) {      // rare: the records straight from memory
+            for (uint32_t k = 0; k < count; ++k) {
+                const float4* rec = sc.ell + static_cast<size_t>(first + k) * 6;
+                const float4 i0 = rec[0], i1 = rec[1], i2 = rec[2], m0 = rec[3], m1 = rec[4], m2 = rec[5];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float t = hit_ellipsoid(o[r], d[r], i0, i1, i2, m0, m1, m2);
+                    if (t < best_t[r]) { best_t[r] = t; best_k[r] = first + k; }
+                }
+            }
+        } else if (shared_origin) {
+            ellipsoid_tile_closest<R, true>(lds, sc.ell, first, count, o, d, best_t, best_k);
+        } else {
+            ellipsoid_tile_closest<R, false>(lds, sc.ell, first, count, o, d, best_t, best_k);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) if (valid[r]) st.key_ell[slot[r]] = best_k[r] == 0xFFFFFFFFu ? NO_HIT_KEY : pack_hit(best_t[r], best_k[r]);
+}
+
+// Brute force over the sphere list, like k_closest_sph, for workgroups whose rays start at one point (rays from the eye):
+// centre - origin and its square are then properties of the sphere, computed once per tile with the expressions of
+// sphere_front, and a pair costs one dot product and three more operations.
+template <int R>
+__global__ void __launch_bounds__(BLOCK) k_closest_sph_eye(DevScene sc, State st, uint32_t bounce) {
+    __shared__ float4 lds[TILE_PRIMS];
+    __shared__ float lds_r2[TILE_PRIMS];
+    const uint32_t n_rays = st.counts[bounce];
+    const uint32_t base = blockIdx.x * (BLOCK * R);
+    if (base >= n_rays) return;
+    uint32_t slot[R];
+    bool valid[R];
+    V3 o[R], d[R];
+    load_rays<R>(st, st.list[bounce & 1u], base, n_rays, slot, valid, o, d);
+    float best_t[R]; uint32_t best_k[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { best_t[r] = FLT_MAX; best_k[r] = 0xFFFFFFFFu; }
+    V3 o_block;
+    const bool shared_origin = workgroup_shares_origin<R>(o, true, o_block);
+    for (uint32_t first = 0; first < sc.n_sph; first += TILE_PRIMS) {
+        const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_sph - first);
+        __syncthreads();
+        if (threadIdx.x < count) {
+            const float4 s = sc.sph[first + threadIdx.x];
+            if (shared_origin) {
+                const V3 oc = sub(xyz(s), o_block);
+                lds[threadIdx.x] = make_float4(oc.x, oc.y, oc.z, vdot(oc, oc));
+                lds_r2[threadIdx.x] = s.w * s.w;
+            } else {
+                lds[threadIdx.x] = s;
+            }
+        }
+        __syncthreads();
+        for (uint32_t k = 0; k < count; ++k) {
+            const float4 s = lds[k];
+            SphereFront front[R];
+            Mask missed = ~0ull;
+            if (shared_origin) {
+                const float r2 = lds_r2[k];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    front[r].mid = vdot(xyz(s), d[r]);
+                    const float mid2 = front[r].mid * front[r].mid;
+                    const float perp2 = s.w - mid2;
+                    front[r].disc = r2 - perp2;
+                    missed &= ballot(front[r].disc < 0.0f);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) { front[r] = sphere_front(o[r], d[r], s); missed &= ballot(front[r].disc < 0.0f); }
+            }
+            if (missed == ballot(true)) continue;      // no lane of the wave has a real root
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float t = sphere_roots(front[r]);
+                if (t < best_t[r]) { best_t[r] = t; best_k[r] = first + k; }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) if (valid[r]) st.key_sph[slot[r]] = best_k[r] == 0xFFFFFFFFu ? NO_HIT_KEY : pack_hit_signed(best_t[r], best_k[r]);
+}
+
 // k_hit: one ray per thread.  Kind choice (ray_tracing.cpp:610-680), hit point, normal,
 // ambient + emission (:682), the reflected ray, and the flag "this ray goes on" for the list compaction.
 __global__ void __launch_bounds__(BLOCK) k_hit(DevScene sc, State st, uint32_t bounce) {
@@ -2381,8 +2699,12 @@ __global__ void __launch_bounds__(BLOCK) RT_SHADOW_BRUTE_ATTR k_shadow_tri_brute
             const Mask testing = ballot(active && !blocked && left != 0u);
             if (testing != 0) {
                 wave_tests += static_cast<unsigned long long>(count) * static_cast<uint32_t>(__popcll(testing));
+                // Only the lanes in `testing` have a specified result: a lane whose ray has been once round the list (left == 0) waits
+                // for the next refill with an open ray, and a pair the staged form is unsure of comes back as a hit unless a lane
+                // that counts is unsure too (brute_force_tile) - it must not block that ray.
+                const bool counted = active && left != 0u;
                 brute_force_tile<1, STAGED, false>(lds, first, count, o, d, staged_wave && !as_written, testing, [&](int, uint32_t, float t) __attribute__((always_inline)) {
-                    blocked |= t < limit;
+                    blocked |= (t < limit) & counted;
                 });
             }
             left -= left != 0u ? 1u : 0u;
@@ -2881,6 +3203,145 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_ell(DevScene sc, State st, uin
     store_shadow_result<R>(st, s, light_bit, stat_slot(st, ST_SHADOW_TESTS_ELL), wave_tests);
 }
 
+
+// Brute-force any-hit over the ellipsoids (PRIM 1, the test in stages) or the spheres (PRIM 2) toward light
+// first_light + blockIdx.y.  These scans follow the triangles' scan, which in a dense scene has blocked most rays already:
+// a workgroup therefore owns a range of the ray list (blocks_per_wg x BLOCK entries), collects the rays of the range that
+// are still open, in order, and scans the primitive list once per BLOCK x R of them, so that its waves hold open rays only
+// (the scans as written below, k_shadow_sph / k_shadow_ell, load every ray of the list and run a wave to the end of the
+// primitive list for its one open ray).  Tests are counted like there: primitives of the tiles staged while the ray was open.
+#ifndef RT_SMALL_SHADOW_RANGE_BLOCKS
+#define RT_SMALL_SHADOW_RANGE_BLOCKS 16
+#endif
+constexpr uint32_t SMALL_SHADOW_RANGE_BLOCKS = RT_SMALL_SHADOW_RANGE_BLOCKS;
+template <int R>
+DEV void ellipsoid_tile_shadow(const float4* lds, uint32_t count, ShadowRays<R>& s, bool point) {
+    for (uint32_t k = 0; k < count; ++k) {
+        const float4 i0 = lds[k], i1 = lds[TILE_PRIMS + k], i2 = lds[2 * TILE_PRIMS + k];
+        EllParts e[R];
+        Mask open = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            e[r] = ell_parts(i0, i1, i2, s.o[r], s.d[r]);
+            open |= ballot(!ell_certain_miss(e[r], ell_margin_term(e[r].oo)) && s.valid[r] && !s.blocked[r]);
+        }
+        if (open == 0) continue;
+        const float4 l2 = lds[3 * TILE_PRIMS + k];
+#pragma unroll
+        for (int r = 0; r < R; ++r) s.blocked[r] |= ell_root_blocks(e[r], ell_root(e[r]), point, xyz(l2));
+    }
+}
+template <int R, int PRIM>
+__global__ void __launch_bounds__(BLOCK) k_shadow_brute(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first) {
+    static_assert(PRIM == 1 || PRIM == 2, "ellipsoids or spheres");
+    constexpr uint32_t PARTS = PRIM == 1 ? 4 : 1, CAPACITY = BLOCK * R;
+    __shared__ float4 lds[TILE_PRIMS * PARTS];
+    __shared__ uint32_t open_slot[CAPACITY + BLOCK];      // the open rays collected so far, in list order
+    __shared__ uint32_t wave_open[BLOCK / 64];
+    const uint32_t n_rays = st.counts[bounce + 1];
+    const uint32_t n_blocks = (n_rays + BLOCK - 1) / BLOCK;
+    const uint32_t blocks_per_wg = min(SMALL_SHADOW_RANGE_BLOCKS, max(1u, n_blocks * gridDim.y / SHADOW_MIN_RANGES));
+    if (static_cast<unsigned long long>(blockIdx.x) * blocks_per_wg >= n_blocks) return;      // (also: no rays)
+    uint32_t next = blockIdx.x * blocks_per_wg * BLOCK;                                        // the next entry of the range to look at
+    const uint32_t range_end = static_cast<uint32_t>(min(static_cast<unsigned long long>(n_rays), static_cast<unsigned long long>(next) + static_cast<unsigned long long>(blocks_per_wg) * BLOCK));
+    const uint32_t light = first_light + blockIdx.y;
+    const float* __restrict__ L = sc.lights + light * 8;
+    const bool point = L[0] != 0.0f;
+    const V3 lv{L[1], L[2], L[3]};
+    const uint32_t light_bit = 1u << (light - group_first);
+    const uint32_t* __restrict__ list = st.list[(bounce + 1) & 1u];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n_prims = PRIM == 1 ? sc.n_ell : sc.n_sph;
+    const float4* light_row = (PRIM == 1 && point) ? sc.ell_light + static_cast<size_t>(light - sc.has_directional) * sc.n_ell : nullptr;
+    uint32_t n_open = 0;
+    unsigned long long wave_tests = 0;
+    for (;;) {
+        while (n_open < CAPACITY && next < range_end) {       // uniform over the workgroup
+            const uint32_t i = next + threadIdx.x;
+            uint32_t slot = 0;
+            bool is_open = false;
+            if (i < range_end) { slot = list[i]; is_open = (st.blocked[slot] & light_bit) == 0u; }
+            const Mask mask = ballot(is_open);
+            if (lane == 0) wave_open[wave] = static_cast<uint32_t>(__popcll(mask));
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < BLOCK / 64; ++w) { const uint32_t c = wave_open[w]; before += w < wave ? c : 0u; total += c; }
+            if (is_open) open_slot[n_open + before + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)))] = slot;
+            __syncthreads();
+            n_open += total;
+            next += BLOCK;
+        }
+        if (n_open == 0) break;
+        const uint32_t take = min(n_open, CAPACITY);
+        ShadowRays<R> s;
+        bool tame = true;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t idx = r * BLOCK + threadIdx.x;
+            s.valid[r] = idx < take;
+            s.slot[r] = open_slot[s.valid[r] ? idx : 0u];          // lanes without a ray repeat the first one and store nothing
+            const ShadowRay ray = make_shadow_ray(st, s.slot[r], point, lv);
+            s.o[r] = ray.o; s.d[r] = ray.d; s.limit[r] = ray.limit;
+            s.blocked[r] = false;
+            tame = tame && ray_is_tame_for_ellipsoids(ray.o, ray.d);
+        }
+        const bool staged_wave = __all(tame);
+        bool done = false;
+        for (uint32_t first = 0; first < n_prims; first += TILE_PRIMS) {
+            const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), n_prims - first);
+            if (__syncthreads_and(done)) break;
+            if (PRIM == 1) {
+                const bool as_written = __syncthreads_or(stage_ellipsoid_tile(lds, sc, first, count, false, V3{0.0f, 0.0f, 0.0f}, light_row));
+                if (!done) {
+                    wave_tests += shadow_live_tests<R>(s, count);
+                    if (as_written || !staged_wave) {      // rare: the records straight from memory
+                        for (uint32_t k = 0; k < count; ++k) {
+                            const float4* rec = sc.ell + static_cast<size_t>(first + k) * 6;
+                            const float4 i0 = rec[0], i1 = rec[1], i2 = rec[2];
+                            const float4 l2 = light_row ? light_row[first + k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+                            for (int r = 0; r < R; ++r) s.blocked[r] |= ellipsoid_blocks(s.o[r], s.d[r], i0, i1, i2, point, xyz(l2));
+                        }
+                    } else {
+                        ellipsoid_tile_shadow<R>(lds, count, s, point);
+                    }
+                }
+            } else {
+                stage_tile<1>(lds, sc.sph, first, count);
+                __syncthreads();
+                if (!done) {
+                    wave_tests += shadow_live_tests<R>(s, count);
+                    for (uint32_t k = 0; k < count; ++k) {
+                        const float4 sp = lds[k];
+                        SphereFront front[R];
+                        Mask missed = ~0ull;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) { front[r] = sphere_front(s.o[r], s.d[r], sp); missed &= ballot(front[r].disc < 0.0f); }
+                        if (missed == ballot(true)) continue;      // no lane of the wave has a real root
+#pragma unroll
+                        for (int r = 0; r < R; ++r) s.blocked[r] |= sphere_roots(front[r]) < s.limit[r];
+                    }
+                }
+            }
+            if (!done) done = shadow_wave_done<R>(s);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (s.valid[r] && s.blocked[r]) atomicOr(&st.blocked[s.slot[r]], light_bit);
+        // the rays collected beyond this batch move to the front
+        __syncthreads();
+        const uint32_t left = n_open - take;
+        uint32_t keep = 0;
+        if (threadIdx.x < left) keep = open_slot[take + threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x < left) open_slot[threadIdx.x] = keep;
+        __syncthreads();
+        n_open = left;
+    }
+    if (lane == 0 && wave_tests) atomicAdd(stat_slot(st, PRIM == 1 ? ST_SHADOW_TESTS_ELL : ST_SHADOW_TESTS_SPH), wave_tests);
+}
+
 // ------------------------------------------------------------------------------------------
 // k_shade: lights [first_light, first_light + n_group) in order; the last group also reflects
 // ------------------------------------------------------------------------------------------
@@ -3035,6 +3496,58 @@ __global__ void __launch_bounds__(BLOCK) k_debug_eval(int op, uint32_t n, const 
         if (store) out[j] = t;
         break;
     }
+    case RT_DEBUG_ELLIPSOID:
+    case RT_DEBUG_ELLIPSOID_STAGED: {   // a: rows of the inverse transform, rows of the transform per item (24); b: origin, direction per item
+        float4 rec[6];
+        for (int row = 0; row < 6; ++row) rec[row] = make_float4(a[j * 24 + row * 4], a[j * 24 + row * 4 + 1], a[j * 24 + row * 4 + 2], a[j * 24 + row * 4 + 3]);
+        const V3 o{b[j * 6], b[j * 6 + 1], b[j * 6 + 2]}, d{b[j * 6 + 3], b[j * 6 + 4], b[j * 6 + 5]};
+        float t = hit_ellipsoid(o, d, rec[0], rec[1], rec[2], rec[3], rec[4], rec[5]);
+        if (op == RT_DEBUG_ELLIPSOID) { if (store) out[j] = t; break; }
+        float stage = 3.0f;     // 3: the test as written (the scans take records and rays outside the staged form's range through it)
+        if (ell_record_is_regular(rec) && ray_is_tame_for_ellipsoids(o, d)) {
+            const EllParts e = ell_parts(rec[0], rec[1], rec[2], o, d);
+            if (ell_certain_miss(e, ell_margin_term(e.oo))) { t = FLT_MAX; stage = 0.0f; }
+            else {
+                const EllRoot root = ell_root(e);
+                if (ell_root_is_out(root)) { t = FLT_MAX; stage = 1.0f; }
+                else { t = ell_world_distance(o, e, root, rec[3], rec[4], rec[5]); stage = 2.0f; }
+            }
+        }
+        if (store) { out[j * 2] = t; out[j * 2 + 1] = stage; }
+        break;
+    }
+    case RT_DEBUG_ELLIPSOID_SHADOW:
+    case RT_DEBUG_ELLIPSOID_SHADOW_STAGED: {   // a: rows of the inverse transform (12), light position (3), 1 for a point light else 0, per item; b: origin, direction per item
+        float4 rec[6];
+        for (int row = 0; row < 3; ++row) rec[row] = make_float4(a[j * 16 + row * 4], a[j * 16 + row * 4 + 1], a[j * 16 + row * 4 + 2], a[j * 16 + row * 4 + 3]);
+        rec[3] = make_float4(1.0f, 0.0f, 0.0f, 0.0f); rec[4] = make_float4(0.0f, 1.0f, 0.0f, 0.0f); rec[5] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);   // (the shadow test does not use the transform)
+        const bool point = a[j * 16 + 15] != 0.0f;
+        const V3 l2 = vmat_point(rec[0], rec[1], rec[2], V3{a[j * 16 + 12], a[j * 16 + 13], a[j * 16 + 14]});     // as k_prep_ellipsoid_lights
+        const V3 o{b[j * 6], b[j * 6 + 1], b[j * 6 + 2]}, d{b[j * 6 + 3], b[j * 6 + 4], b[j * 6 + 5]};
+        bool blocked = ellipsoid_blocks(o, d, rec[0], rec[1], rec[2], point, l2);
+        if (op == RT_DEBUG_ELLIPSOID_SHADOW) { if (store) out[j] = blocked ? 1.0f : 0.0f; break; }
+        float stage = 3.0f;
+        const bool light_fits = !point || fmaxf(fabsf(l2.x), fmaxf(fabsf(l2.y), fabsf(l2.z))) <= ELL_LIGHT_COORD;
+        if (ell_record_is_regular(rec) && light_fits && ray_is_tame_for_ellipsoids(o, d)) {
+            const EllParts e = ell_parts(rec[0], rec[1], rec[2], o, d);
+            if (ell_certain_miss(e, ell_margin_term(e.oo))) { blocked = false; stage = 0.0f; }
+            else { blocked = ell_root_blocks(e, ell_root(e), point, l2); stage = 1.0f; }
+        }
+        if (store) { out[j * 2] = blocked ? 1.0f : 0.0f; out[j * 2 + 1] = stage; }
+        break;
+    }
+    case RT_DEBUG_ELLIPSOID_PARTS: {    // a: rows of the inverse transform per item (12); b: origin, direction per item
+        const float4 i0 = make_float4(a[j * 12], a[j * 12 + 1], a[j * 12 + 2], a[j * 12 + 3]), i1 = make_float4(a[j * 12 + 4], a[j * 12 + 5], a[j * 12 + 6], a[j * 12 + 7]),
+                     i2 = make_float4(a[j * 12 + 8], a[j * 12 + 9], a[j * 12 + 10], a[j * 12 + 11]);
+        const V3 o{b[j * 6], b[j * 6 + 1], b[j * 6 + 2]}, d{b[j * 6 + 3], b[j * 6 + 4], b[j * 6 + 5]};
+        const V3 o2 = vmat_point(i0, i1, i2, o);                         // Mat3x4AVX * Vec3AVX, ray_tracing.cpp:105-126
+        const V3 d2 = vmat_dir(i0, i1, i2, d);                           // transform_direction, :208-227
+        const bool absent = (d2.x < TOL) & (d2.y < TOL) & (d2.z < TOL);  // ellipsoid_is_absent, :336-344
+        const V3 unit = scale(1.0f / sqrt_(vdot(d2, d2)), d2);           // :564-566
+        const float t2 = hit_unit_sphere(o2, unit);                      // intersect_with_unit_sphere, :229-263
+        if (store) { float* q = out + j * 8; q[0] = o2.x; q[1] = o2.y; q[2] = o2.z; q[3] = d2.x; q[4] = d2.y; q[5] = d2.z; q[6] = absent ? 1.0f : 0.0f; q[7] = t2; }
+        break;
+    }
     default: break;
     }
 }
@@ -3075,6 +3588,8 @@ struct FrameSlot {
     int rc = 0;
     std::string error;
     rt_stats stats_out;
+    // a frame begun and never ended is still completed: its thread is joined when the library is unloaded
+    ~FrameSlot() { if (worker.joinable()) worker.join(); }
 };
 struct Library {
     bool ready = false;
@@ -3082,7 +3597,8 @@ struct Library {
     FrameSlot slots[FRAME_SLOTS];
     hipStream_t stream = nullptr;           // = slots[0].lanes[0].stream: uploads, scene preparation, assembly
     unsigned char* scratch = nullptr;       // device address of `scratch` on this device (hipGetSymbolAddress)
-    std::mutex guard;                       // scene creation, box rebuilds, assembly, the test hook: one at a time
+    std::mutex guard;                       // scene creation, assembly, the test hook: one at a time
+    std::mutex frames_guard;                // rt_render_tiles_begin / _end: which slot holds a begun frame
     // multi-GPU (rt_comm_*, rt_init_devices): this device's rank in a communicator, a stream for the exchange, tile buffers
     void* comm = nullptr;                   // ncclComm_t
     int comm_rank = 0, comm_world = 1;
@@ -3106,11 +3622,22 @@ Library& current_device() {
     return first ? *first : g_devices[0];
 }
 // Binds the calling thread to a device context (and makes its HIP device current) for the life of the object.
+// The thread's HIP device is put back as it was found, whether or not the thread had a binding before: a caller's thread
+// that was never bound resolves to the first context (current_device) and must find that context's device current again.
 struct DeviceBinding {
     Library* before;
+    int device_before = -1;
     bool ok;
-    explicit DeviceBinding(Library& lib) : before(t_device), ok(hipSetDevice(lib.device) == hipSuccess) { t_device = &lib; }
-    ~DeviceBinding() { t_device = before; if (before) (void)hipSetDevice(before->device); }
+    explicit DeviceBinding(Library& lib) : before(t_device) {
+        if (hipGetDevice(&device_before) != hipSuccess) device_before = -1;
+        ok = hipSetDevice(lib.device) == hipSuccess;
+        t_device = &lib;
+    }
+    ~DeviceBinding() {
+        t_device = before;
+        const int back = before ? before->device : device_before;
+        if (back >= 0) (void)hipSetDevice(back);
+    }
 };
 
 #ifndef RT_RAYS_PER_LANE
@@ -3187,9 +3714,11 @@ struct rt_scene {
     int device = -1;                   // the HIP device these allocations live on
     rt_scene* next = nullptr;          // the replica on the next device of a single-process multi-GPU set-up (rt_init_devices)
     std::vector<void*> allocations;
-    // bound of ray origins the box records were built for; grows (records rebuilt) when a camera's eye lies outside it:
-    // one render at a time per scene
+    // bound of ray origins the box records were built for; grows (records rebuilt) when a camera's eye lies outside it.
+    // Every frame reads the records under a shared lock for as long as it is traced; a rebuild takes the lock exclusively,
+    // i.e. waits for the frames in flight on any slot, and is complete on the device before it lets go.
     mutable float box_bound = 0.0f;
+    mutable std::shared_mutex boxes;
     bool directional_is_unit = true;   // |direction|^2 <= 1 + 20 * 2^-24: the shadow scans toward it may use the pre-tests
 };
 
@@ -3374,15 +3903,20 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     if (!scene) return rt_fail(RT_ERR_ARGUMENT, "the scene has no replica on this device");
     DevScene sc = scene->dev;
     hipStream_t stream = slot.lanes[0].stream;
+    std::shared_lock<std::shared_mutex> reading(scene->boxes, std::defer_lock);   // held until this frame's launches have completed
     {   // the box records must hold for the eye as an origin too
         float need = sc.origin_bound;
         for (int i = 0; i < 3; ++i) need = std::fmax(need, 1.001f * std::fabs(cam->eye[i]) + 1.0e-3f);
-        if (!(need <= scene->box_bound)) {
-            if (!std::isfinite(need)) return rt_fail(RT_ERR_ARGUMENT, "camera eye is not finite");
-            std::lock_guard<std::mutex> rebuild(lib.guard);
-            if (!(need <= scene->box_bound)) {      // (rt_render_tiles_begin has done this already, with no other frame in flight)
+        if (!std::isfinite(need)) return rt_fail(RT_ERR_ARGUMENT, "camera eye is not finite");
+        for (;;) {
+            reading.lock();
+            if (need <= scene->box_bound) break;
+            reading.unlock();
+            std::unique_lock<std::shared_mutex> rebuilding(scene->boxes);
+            if (!(need <= scene->box_bound)) {
                 build_boxes(scene, need, stream);
                 HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(stream));
             }
         }
         sc.box_bound = scene->box_bound;
@@ -3521,11 +4055,13 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                     }
                 });
                 if (sc.n_sph) timed(timer, 3, on, [&] {
-                    if (!walk[2]) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b);
+                    if (!walk[2] && b == 0 && !plain_test) hipLaunchKernelGGL(k_closest_sph_eye<RAYS_PER_LANE>, dim3(scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b);
+                    else if (!walk[2]) hipLaunchKernelGGL(k_closest_sph<RAYS_PER_LANE>, dim3(scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b);
                     else hierarchy_scan(2);
                 });
                 if (sc.n_ell) timed(timer, 4, on, [&] {
-                    if (!walk[1]) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b);
+                    if (!walk[1] && plain_test) hipLaunchKernelGGL(k_closest_ell<RAYS_PER_LANE>, dim3(scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b);
+                    else if (!walk[1]) hipLaunchKernelGGL(k_closest_ell_staged<RAYS_PER_LANE>, dim3(scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b);
                     else hierarchy_scan(1);
                 });
             });
@@ -3591,8 +4127,11 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                             }
                             hipLaunchKernelGGL((k_shadow_tri_brute<true>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0, list);
                         }
-                        else if (prim == 1) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
-                        else hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
+                        else if (prim == 1 && plain_test) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
+                        else if (prim == 2 && plain_test) hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
+                        // (these two cut the ray list into ranges of their own, like the triangle scan: a workgroup beyond the last range returns)
+                        else if (prim == 1) hipLaunchKernelGGL((k_shadow_brute<RAYS_PER_LANE, 1>), dim3(ray_blocks(), n), dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
+                        else hipLaunchKernelGGL((k_shadow_brute<RAYS_PER_LANE, 2>), dim3(ray_blocks(), n), dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                     };
                     timed(timer, 1, stream, [&] {
                         const uint32_t count[3] = {sc.n_tri, sc.n_ell, sc.n_sph};
@@ -4065,12 +4604,14 @@ static int scene_create_impl(const rt_scene_desc* desc, SceneOrders& orders, rt_
     d.tri_mat = tri_mat; d.sph_mat = sph_mat; d.ell_mat = ell_mat;
 
     float4 *tri, *trif, *sph, *ell, *ell_light;
+    float* ell_ok;
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &tri))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_tri) * 4, &trif))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, d.n_sph, &sph))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * 6, &ell))) return fail(rc);
     if ((rc = upload<float4>(s, nullptr, static_cast<size_t>(d.n_ell) * desc->n_point_lights, &ell_light))) return fail(rc);
-    d.tri = tri; d.trif = trif; d.sph = sph; d.ell = ell; d.ell_light = ell_light;
+    if ((rc = upload<float>(s, nullptr, d.n_ell, &ell_ok))) return fail(rc);
+    d.tri = tri; d.trif = trif; d.sph = sph; d.ell = ell; d.ell_light = ell_light; d.ell_ok = ell_ok;
     {
         float b = 0.0f;
         for (int i = 0; i < 6; ++i) b = std::fmax(b, std::fabs(desc->bounding_box[i]));
@@ -4078,7 +4619,7 @@ static int scene_create_impl(const rt_scene_desc* desc, SceneOrders& orders, rt_
     }
     if (d.n_tri) hipLaunchKernelGGL(k_prep_triangles, dim3(ceil_div(d.n_tri, BLOCK)), dim3(BLOCK), 0, stream, raw_tri, d.tri_nb, tri, trif);
     if (d.n_sph) hipLaunchKernelGGL(k_prep_spheres, dim3(ceil_div(d.n_sph, BLOCK)), dim3(BLOCK), 0, stream, raw_sph, d.sph_nb, sph);
-    if (d.n_ell) hipLaunchKernelGGL(k_prep_ellipsoids, dim3(ceil_div(d.n_ell, BLOCK)), dim3(BLOCK), 0, stream, raw_inv, raw_fwd, d.ell_nb, ell);
+    if (d.n_ell) hipLaunchKernelGGL(k_prep_ellipsoids, dim3(ceil_div(d.n_ell, BLOCK)), dim3(BLOCK), 0, stream, raw_inv, raw_fwd, d.ell_nb, ell, ell_ok);
     if (d.n_ell && desc->n_point_lights)
         hipLaunchKernelGGL(k_prep_ellipsoid_lights, dim3(ceil_div(d.n_ell, BLOCK)), dim3(BLOCK), 0, stream, ell, d.n_ell, raw_pl, static_cast<uint32_t>(desc->n_point_lights), ell_light);
 
@@ -4182,23 +4723,15 @@ int rt_render_tiles_begin(const rt_scene* scene, const rt_camera_desc* camera, c
     if (!lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
     if (!scene || !camera || !params || !tiles_dev || !ticket) return rt_fail(RT_ERR_ARGUMENT, "rt_render_tiles_begin: null argument");
     return guarded([&]() -> int {
+        std::lock_guard<std::mutex> frames(lib.frames_guard);     // begin and end from any threads: one at a time
         int free_slot = -1;
         for (int i = 0; i < FRAME_SLOTS; ++i) if (!lib.slots[i].busy) { free_slot = i; break; }
         if (free_slot < 0) return rt_fail(RT_ERR_LIMIT, "rt_render_tiles_begin: two frames are in flight already (rt_render_tiles_end)");
-        {   // box records that do not cover this camera are rebuilt here, while no other frame reads them
+        {
             const rt_scene* replica = scene;
             while (replica && replica->device != lib.device) replica = replica->next;
             if (!replica) return rt_fail(RT_ERR_ARGUMENT, "the scene has no replica on this device");
-            float need = replica->dev.origin_bound;
-            for (int i = 0; i < 3; ++i) need = std::fmax(need, 1.001f * std::fabs(camera->eye[i]) + 1.0e-3f);
-            if (!(need <= replica->box_bound)) {
-                if (!std::isfinite(need)) return rt_fail(RT_ERR_ARGUMENT, "camera eye is not finite");
-                for (FrameSlot& other : lib.slots) if (other.busy && other.worker.joinable()) other.worker.join();   // still busy: its ticket stays good until _end
-                std::lock_guard<std::mutex> rebuild(lib.guard);
-                build_boxes(replica, need, lib.stream);
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipStreamSynchronize(lib.stream));
-            }
+            for (int i = 0; i < 3; ++i) if (!std::isfinite(camera->eye[i])) return rt_fail(RT_ERR_ARGUMENT, "camera eye is not finite");
         }
         FrameSlot& slot = lib.slots[free_slot];
         slot.busy = true;
@@ -4219,6 +4752,7 @@ int rt_render_tiles_begin(const rt_scene* scene, const rt_camera_desc* camera, c
 int rt_render_tiles_end(int ticket, rt_stats* stats) {
     Library& lib = current_device();
     if (!lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    std::lock_guard<std::mutex> frames(lib.frames_guard);
     if (ticket < 0 || ticket >= FRAME_SLOTS || !lib.slots[ticket].busy) return rt_fail(RT_ERR_ARGUMENT, "rt_render_tiles_end: no frame in flight under this ticket");
     FrameSlot& slot = lib.slots[ticket];
     if (slot.worker.joinable()) slot.worker.join();
@@ -4306,7 +4840,9 @@ int rt_debug_eval(int op, uint32_t n, const float* a, const float* b, float* out
     static const struct { int op; uint32_t a_per_item, a_fixed, b_per_item, out_per_item; } shapes[] = {
         {RT_DEBUG_FP_POW, 1, 0, 1, 1}, {RT_DEBUG_FP_MIN, 1, 0, 1, 1}, {RT_DEBUG_FP_MAX, 1, 0, 1, 1}, {RT_DEBUG_DIVIDE, 1, 0, 1, 1},
         {RT_DEBUG_DIVIDE_IN_RANGE, 1, 0, 1, 1}, {RT_DEBUG_PRIMARY_RAY, 0, 16, 4, 3}, {RT_DEBUG_SCENE_BOX, 0, 6, 6, 2},
-        {RT_DEBUG_TRIANGLE, 9, 0, 6, 1}, {RT_DEBUG_TRIANGLE_STAGED, 9, 0, 6, 1}, {RT_DEBUG_SPHERE, 4, 0, 6, 1}};
+        {RT_DEBUG_TRIANGLE, 9, 0, 6, 1}, {RT_DEBUG_TRIANGLE_STAGED, 9, 0, 6, 1}, {RT_DEBUG_SPHERE, 4, 0, 6, 1},
+        {RT_DEBUG_ELLIPSOID, 24, 0, 6, 1}, {RT_DEBUG_ELLIPSOID_STAGED, 24, 0, 6, 2}, {RT_DEBUG_ELLIPSOID_SHADOW, 16, 0, 6, 1},
+        {RT_DEBUG_ELLIPSOID_SHADOW_STAGED, 16, 0, 6, 2}, {RT_DEBUG_ELLIPSOID_PARTS, 12, 0, 6, 8}};
     const auto* shape = &shapes[0];
     bool found = false;
     for (const auto& sh : shapes) if (sh.op == op) { shape = &sh; found = true; }

@@ -30,6 +30,8 @@ def _common_protos(prefix):
         prefix + "intersect_aabb": (None, [_P(_f3), _P(_f3), _P(C.c_float * 6), _P(C.c_float * 2)]),
         prefix + "intersect_triangle8": (None, [_P(_f3), _P(_f3), C.c_void_p, _P(C.c_float * 8)]),
         prefix + "intersect_sphere8": (None, [_P(_f3), _P(_f3), C.c_void_p, _P(C.c_float * 8)]),
+        prefix + "ellipsoid8": (None, [_P(_f3), _P(_f3), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+        prefix + "ellipsoid8_blocks": (C.c_int, [_P(_f3), _P(_f3), C.c_int, C.c_void_p, _P(_f3)]),
         prefix + "trace": (None, [_P(abi.SceneDesc), _P(_f3), _P(_f3), C.c_int, _P(_f3)]),
         prefix + "camera_setup": (None, [_P(C.c_float * 11), _P(abi.CameraDesc)]),
     }

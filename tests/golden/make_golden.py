@@ -12,6 +12,9 @@ Outputs
   tests/golden/parsed.json        : SHA-256 of every array parse_input_file produces, per scene
   tests/golden/known_answers.npz  : random inputs and the reference's outputs for fp_pow, fp_min/max,
                                     ray_direction_through_pixel, the AABB test, Triangle8 / Sphere8 tests
+  tests/golden/known_answers_ellipsoid.npz : the same for the ellipsoid routines (closest-hit body, shadow body)
+
+    python tests/golden/make_golden.py ellipsoids     # only the last file
 """
 import ctypes as C
 import hashlib
@@ -49,8 +52,108 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def ellipsoid_batch(rng, zero_from=8):
+    """One Mat3x4x8 pair: M = translate * rotate * scale per lane, inverse via float64; lanes >= zero_from are padding (zeros)."""
+    inv8 = np.zeros((3, 4, 8), np.float32)
+    fwd8 = np.zeros((3, 4, 8), np.float32)
+    centres, radii = np.zeros((8, 3)), np.zeros(8)
+    for j in range(min(8, zero_from)):
+        axis = rng.standard_normal(3)
+        axis /= np.linalg.norm(axis)
+        ang = rng.uniform(0, 2 * np.pi)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+        sc = np.exp(rng.uniform(np.log(0.05), np.log(3.0), 3))
+        c = rng.uniform(-4, 4, 3)
+        M = np.eye(4)
+        M[:3, :3] = R @ np.diag(sc)
+        M[:3, 3] = c
+        fwd8[:, :, j] = M[:3].astype(np.float32)
+        inv8[:, :, j] = np.linalg.inv(M)[:3].astype(np.float32)
+        centres[j], radii[j] = c, sc.max()
+    return inv8, fwd8, centres, radii
+
+
+def ellipsoid_known_answers(ref):
+    """Inputs and the reference's outputs for the ellipsoid routines -> known_answers_ellipsoid.npz."""
+    rng = np.random.default_rng(20240808)
+    nb = 384
+    ka = {k: [] for k in ("inv8", "fwd8", "o", "d", "o2", "d2", "absent", "t2", "dist")}
+    checked_ids = 0
+    for b in range(nb):
+        inv8, fwd8, centres, radii = ellipsoid_batch(rng, zero_from=5 if b % 4 == 0 else 8)
+        lane = b % (5 if b % 4 == 0 else 8)
+        if b % 3 == 0:   # origin inside the ellipsoid
+            o = (centres[lane] + rng.uniform(-0.2, 0.2, 3) * 0.05).astype(np.float32)
+        else:
+            o = rng.uniform(-8, 8, 3).astype(np.float32)
+        # aim at the chosen lane: through it, grazing it (offset close to its largest radius), past it
+        offset = rng.standard_normal(3)
+        offset *= radii[lane] * (0.3, 0.97, 1.03, 1.6)[b % 4] / np.linalg.norm(offset)
+        d = (centres[lane] + offset - o)
+        d = (d / np.linalg.norm(d)).astype(np.float32)
+        if b % 7 == 0:
+            d = -d       # the ellipsoid behind the ray
+        out = [np.zeros(24, np.float32), np.zeros(24, np.float32), np.zeros(8, np.float32), np.zeros(8, np.float32), np.zeros(8, np.float32)]
+        ref.ref_ellipsoid8(C.byref(checkers.vec3(o)), C.byref(checkers.vec3(d)), inv8.ctypes.data, fwd8.ctypes.data, *[x.ctypes.data for x in out])
+        # the closest-hit body is inline in intersect(Ray, Scene, int): check the composed distances against that function's choice
+        n_real = 5 if b % 4 == 0 else 8
+        mats = np.zeros((n_real, 10), np.float32)
+        mats[:, 8] = np.arange(1, n_real + 1)       # emission blue = index + 1
+        desc = abi.SceneDesc()
+        desc.ellipsoid8_inverse_transforms = inv8.ctypes.data_as(abi.c_float_p)
+        desc.ellipsoid8_transforms = fwd8.ctypes.data_as(abi.c_float_p)
+        desc.ellipsoid_materials = mats.ctypes.data_as(abi.c_float_p)
+        desc.n_ellipsoid8, desc.n_ellipsoids = 1, n_real
+        col = (C.c_float * 3)()
+        ref.ref_trace(C.byref(desc), C.byref(checkers.vec3(o)), C.byref(checkers.vec3(d)), 1, C.byref(col))
+        dist = out[4]
+        want = 0
+        if (dist < np.float32(3.4028234663852886e38)).any():
+            want = int(np.argmin(dist)) + 1     # first lane among equal distances: the reference scans lanes with a strict <
+        if want <= n_real:                      # (a hit on a padding lane reads a material past the vector)
+            assert int(col[2]) == want, (b, list(col), dist)
+            checked_ids += 1
+        for k, v in zip(("inv8", "fwd8", "o", "d", "o2", "d2", "absent", "t2", "dist"), (inv8.reshape(-1), fwd8.reshape(-1), o, d, *out)):
+            ka[k].append(v.copy())
+    ka = {k: np.array(v, np.float32) for k, v in ka.items()}
+    print("ellipsoid closest-hit bodies: %d batches, %d lanes hit, %d absent, choice checked against intersect() on %d batches"
+          % (nb, int((ka["dist"] < 3e38).sum()), int(ka["absent"].sum()), checked_ids))
+
+    # shadow body: path_is_blocked on one ellipsoid at a time (the other lanes of the batch are padding)
+    n = 3072
+    sh = {k: [] for k in ("inv", "start", "light", "point", "dir", "blocked")}
+    for i in range(n):
+        inv8, fwd8, centres, radii = ellipsoid_batch(rng, zero_from=1)
+        point = i % 3 != 0
+        start = rng.uniform(-8, 8, 3).astype(np.float32)
+        offset = rng.standard_normal(3)
+        offset *= radii[0] * (0.3, 0.97, 1.03, 1.6)[i % 4] / np.linalg.norm(offset)
+        through = centres[0] + offset
+        if point:
+            # the light beyond the ellipsoid, in front of it, or inside it
+            light = (start + (through - start) * (2.0, 0.5, 1.0, 3.0, 0.97)[i % 5]).astype(np.float32)
+        else:
+            light = (start - through)
+            light = (light / np.linalg.norm(light)).astype(np.float32)      # direction toward which the light travels = -ray direction
+            if i % 8 == 0:
+                light *= np.float32(0.5)                                     # not of unit length
+        dir_out = (C.c_float * 3)()
+        blocked = ref.ref_ellipsoid8_blocks(C.byref(checkers.vec3(start)), C.byref(checkers.vec3(light)), 1 if point else 0, inv8.ctypes.data, C.byref(dir_out))
+        for k, v in zip(("inv", "start", "light", "point", "dir", "blocked"),
+                        (inv8[:, :, 0].reshape(-1), start, light, np.float32(1.0 if point else 0.0), np.array(list(dir_out), np.float32), np.float32(blocked))):
+            sh[k].append(v)
+    for k, v in sh.items():
+        ka["shadow_" + k] = np.array(v, np.float32)
+    print("ellipsoid shadow bodies: %d, %d blocked" % (n, int(ka["shadow_blocked"].sum())))
+    np.savez_compressed(os.path.join(HERE, "known_answers_ellipsoid.npz"), **ka)
+
+
 def main():
     ref = checkers.load_ref()
+    if sys.argv[1:] == ["ellipsoids"]:
+        ellipsoid_known_answers(ref)
+        return
     parsed = {}
     for name in SCENES:
         path = os.path.join(HERE, "scenes", name + ".test")
@@ -179,6 +282,7 @@ def main():
     ka["sph8"], ka["sph_o"], ka["sph_d"], ka["sph_out"] = sph8, sph_o, sph_d, sph_out
     np.savez_compressed(os.path.join(HERE, "known_answers.npz"), **ka)
     print("known answers done")
+    ellipsoid_known_answers(ref)
 
 
 if __name__ == "__main__":

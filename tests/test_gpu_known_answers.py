@@ -134,3 +134,134 @@ def test_in_range_division_is_the_ieee_division(gpu):
     want = gpu.debug_eval(abi.RT_DEBUG_DIVIDE, num, den, 1)
     assert same_bits(want, (num.astype(np.float64) / den.astype(np.float64)).astype(np.float32))    # the device's own IEEE division is correctly rounded
     assert same_bits(gpu.debug_eval(abi.RT_DEBUG_DIVIDE_IN_RANGE, num, den, 1), want)
+
+
+# ---- ellipsoid routines (ray_tracing.cpp:105-126, :208-263, :336-344, :376-401, :432-454, :556-579) ------------------------
+from test_oracle_known_answers import KA_ELL  # noqa: E402
+
+
+def _ellipsoid_lanes():
+    """(batches, 96) Mat3x4x8 pairs + one ray per batch -> per-lane records (batches*8, 24) and rays repeated per lane."""
+    k = KA_ELL
+    n = len(k["o"])
+    inv = k["inv8"].reshape(n, 12, 8).transpose(0, 2, 1).reshape(-1, 12)
+    fwd = k["fwd8"].reshape(n, 12, 8).transpose(0, 2, 1).reshape(-1, 12)
+    rays = np.repeat(np.concatenate([k["o"], k["d"]], axis=1), 8, axis=0)
+    return np.ascontiguousarray(inv), np.ascontiguousarray(fwd), np.ascontiguousarray(rays)
+
+
+def _lanes(x):      # (batches, 3 * 8) stored as x[8] y[8] z[8] -> (batches * 8, 3)
+    return x.reshape(len(x), 3, 8).transpose(0, 2, 1).reshape(-1, 3)
+
+
+def test_ellipsoid_routines(gpu):
+    """Mat3x4AVX * Vec3AVX, transform_direction, ellipsoid_is_absent and intersect_with_unit_sphere, one by one."""
+    inv, fwd, rays = _ellipsoid_lanes()
+    out = gpu.debug_eval(abi.RT_DEBUG_ELLIPSOID_PARTS, inv, rays).reshape(-1, 8)
+    assert same_bits(out[:, 0:3], _lanes(KA_ELL["o2"]))
+    assert same_bits(out[:, 3:6], _lanes(KA_ELL["d2"]))
+    assert np.array_equal(out[:, 6], KA_ELL["absent"].reshape(-1))
+    assert same_bits(out[:, 7], KA_ELL["t2"].reshape(-1))
+
+
+def test_ellipsoid8_batches(gpu):
+    """The closest-hit body as written and in stages against the reference's distances."""
+    inv, fwd, rays = _ellipsoid_lanes()
+    rec = np.concatenate([inv, fwd], axis=1)
+    want = KA_ELL["dist"].reshape(-1)
+    assert same_bits(gpu.debug_eval(abi.RT_DEBUG_ELLIPSOID, rec, rays), want)
+    staged = gpu.debug_eval(abi.RT_DEBUG_ELLIPSOID_STAGED, rec, rays).reshape(-1, 2)
+    hit = want < FLT_MAX
+    assert same_bits(staged[hit, 0], want[hit]) and (staged[hit, 1] == 2).all()
+    assert (staged[~hit, 0] == FLT_MAX).all()         # (misses of a regular record as written are +inf or NaN: not below FLT_MAX either)
+    assert set(np.unique(staged[:, 1])) == {0.0, 1.0, 2.0}
+
+
+def test_ellipsoid_shadow_bodies(gpu):
+    k = KA_ELL
+    a = np.concatenate([k["shadow_inv"], k["shadow_light"], k["shadow_point"][:, None]], axis=1)
+    b = np.concatenate([k["shadow_start"], k["shadow_dir"]], axis=1)
+    assert np.array_equal(gpu.debug_eval(abi.RT_DEBUG_ELLIPSOID_SHADOW, a, b), k["shadow_blocked"])
+    staged = gpu.debug_eval(abi.RT_DEBUG_ELLIPSOID_SHADOW_STAGED, a, b).reshape(-1, 2)
+    assert np.array_equal(staged[:, 0], k["shadow_blocked"])
+    assert (staged[:, 1] == 0).sum() > 100 and (staged[:, 1] == 1).sum() > 100
+
+
+def _random_ellipsoid_pairs(rng, n, extent, scale_lo, scale_hi, graze):
+    """Ellipsoid records (inverse rows, rows) and rays aimed near them; `graze`: share of rays aimed at the silhouette."""
+    axis = rng.normal(size=(n, 3))
+    axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    K = np.zeros((n, 3, 3))
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -axis[:, 2], axis[:, 1], axis[:, 2], -axis[:, 0], -axis[:, 1], axis[:, 0]
+    R = np.eye(3)[None] + np.sin(ang)[:, None, None] * K + (1 - np.cos(ang))[:, None, None] * (K @ K)
+    sc = np.exp(rng.uniform(np.log(scale_lo), np.log(scale_hi), (n, 3)))
+    c = rng.uniform(-extent, extent, (n, 3))
+    A = R * sc[:, None, :]                                   # R @ diag(sc)
+    Ainv = (R / sc[:, None, :]).transpose(0, 2, 1)           # diag(1/sc) @ R^T
+    t_inv = -np.einsum("nij,nj->ni", Ainv, c)
+    rec = np.concatenate([np.concatenate([Ainv, t_inv[:, :, None]], axis=2).reshape(n, 12),
+                          np.concatenate([A, c[:, :, None]], axis=2).reshape(n, 12)], axis=1).astype(np.float32)
+    o = rng.uniform(-extent, extent, (n, 3))
+    inside = rng.random(n) < 0.05
+    o[inside] = c[inside] + rng.uniform(-0.3, 0.3, (inside.sum(), 3)) * sc[inside].min(axis=1, keepdims=True)
+    # a point on (or near) the surface, seen from o: unit vector u in ellipsoid space, scaled around 1 for grazing rays
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    radial = np.where(rng.random(n) < graze, 1.0 + rng.normal(size=n) * 1e-4, rng.uniform(0.0, 2.5, n))
+    target = c + np.einsum("nij,nj->ni", A, u * radial[:, None])
+    # grazing: direction tangent to the surface at that point = orthogonal (in ellipsoid space) to u
+    tangent = np.cross(u, rng.normal(size=(n, 3)))
+    tangent /= np.linalg.norm(tangent, axis=1, keepdims=True)
+    far = target - np.einsum("nij,nj->ni", A, tangent) * rng.uniform(1.0, 30.0, (n, 1))
+    use_tangent = rng.random(n) < graze
+    o = np.where(use_tangent[:, None], far, o)
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[rng.random(n) < 0.1] *= -1.0
+    return rec, np.concatenate([o, d], axis=1).astype(np.float32), c.astype(np.float32)
+
+
+@pytest.mark.parametrize("case", ["ordinary", "small_far", "grazing", "thin", "huge", "out_of_range"])
+def test_staged_ellipsoid_tests_equal_the_plain_ones(gpu, case):
+    """2 M random pairs per case: closest-hit body and shadow body, staged against as written.
+
+    A stage may call a pair decided only when the form as written returns nothing below FLT_MAX (closest hit) or "not blocked";
+    where the staged form returns a distance it must be the same bits."""
+    extent, lo, hi, graze = {"ordinary": (10, 0.05, 3.0, 0.2), "small_far": (300, 0.01, 0.3, 0.3), "grazing": (20, 0.05, 2.0, 1.0),
+                             "thin": (10, 0.001, 3.0, 0.3), "huge": (3000, 5.0, 500.0, 0.3), "out_of_range": (1e5, 0.1, 10.0, 0.2)}[case]
+    rng = np.random.default_rng(sum(map(ord, case)))
+    n = 1 << 21
+    rec, ray, centre = _random_ellipsoid_pairs(rng, n, extent, lo, hi, graze)
+    rec[:64] = 0.0                                           # padding lanes
+    rec[64:128, 0:4] = 0.0                                   # singular inverse transforms: not regular
+    plain = gpu.debug_eval(abi.RT_DEBUG_ELLIPSOID, rec, ray)
+    staged = gpu.debug_eval(abi.RT_DEBUG_ELLIPSOID_STAGED, rec, ray).reshape(-1, 2)
+    stage = staged[:, 1]
+    hit = plain < FLT_MAX                                    # (false for NaN)
+    assert same_bits(staged[hit, 0], plain[hit])
+    assert (stage[hit] >= 2).all()
+    decided = stage < 2
+    assert not (plain[decided] < FLT_MAX).any() and (staged[decided, 0] == FLT_MAX).all()
+    assert same_bits(staged[stage == 3, 0], plain[stage == 3])
+    share = [float((stage == s).mean()) for s in range(4)]
+    print("closest hit: stage 0 %.3f, stage 1 %.3f, tail %.3f, as written %.3f; hits %.3f" % (*share, hit.mean()))
+    if case == "out_of_range":
+        assert share[3] > 0.9
+    else:
+        # (huge: some of the origins the construction places lie beyond the 4096 the staged form is proven for)
+        assert share[3] < (0.1 if case == "huge" else 0.001) and hit.mean() > 0.05 and share[0] > 0.05
+
+    # shadow body: point lights behind, before and inside the ellipsoid, and directional lights
+    point = (rng.random(n) < 0.7).astype(np.float32)
+    along = rng.choice([0.5, 0.97, 1.0, 1.03, 2.0, 5.0], n)
+    reach = np.linalg.norm(centre - ray[:, :3], axis=1)
+    light_pos = ray[:, :3] + ray[:, 3:] * (reach * along)[:, None]
+    light = np.where(point[:, None] > 0, light_pos, -ray[:, 3:]).astype(np.float32)
+    a = np.concatenate([rec[:, :12], light, point[:, None]], axis=1).astype(np.float32)
+    # the direction as the reference derives it from the light (normalised difference) is not bit-equal to ray[:, 3:]; any direction is a valid input
+    plain_s = gpu.debug_eval(abi.RT_DEBUG_ELLIPSOID_SHADOW, a, ray)
+    staged_s = gpu.debug_eval(abi.RT_DEBUG_ELLIPSOID_SHADOW_STAGED, a, ray).reshape(-1, 2)
+    assert np.array_equal(staged_s[:, 0], plain_s)
+    print("shadow: stage 0 %.3f, blocked %.3f" % ((staged_s[:, 1] == 0).mean(), plain_s.mean()))
+    assert case == "out_of_range" or (0.02 < plain_s.mean() < 0.9 and (staged_s[:, 1] == 0).mean() > 0.05)

@@ -78,7 +78,6 @@ def test_long_ray_lists_brute_force_equals_default(gpu, tmp_path):
     fast = scene.render(cam, fi.params(), want_ids=True)
     slow = scene.render(cam, fi.params(flags=abi.RT_FLAG_NO_FILTER), want_ids=True)
     plain = scene.render(cam, fi.params(flags=abi.RT_FLAG_NO_FILTER | abi.RT_FLAG_PLAIN_TEST), want_ids=True)
-    scene.close()
     assert fast["stats"].shadow_rays == 8 * fast["stats"].hits and fast["stats"].hits > 3_200_000      # 12 500 blocks of 256 rays per light
     assert 0 < fast["stats"].shadow_blocked < fast["stats"].shadow_rays
     for other in (slow, plain):
@@ -86,3 +85,11 @@ def test_long_ray_lists_brute_force_equals_default(gpu, tmp_path):
         assert np.array_equal(other["rgb"], fast["rgb"])
         for f in ("samples", "culled", "closest_rays", "hits", "shadow_rays", "shadow_blocked"):
             assert getattr(other["stats"], f) == getattr(fast["stats"], f), f
+    # The brute-force shadow scan takes the hit points in an order that differs from run to run (cells filled by atomics), so
+    # which rays share a wave differs too: a result that depended on a ray's wave mates once showed as one blocked ray more in
+    # 92 M, in one run out of three.  The blocked count is exact where the 8-bit image can hide one lost light.
+    for again in range(5):
+        r = scene.render(cam, fi.params(flags=abi.RT_FLAG_NO_FILTER))
+        assert r["stats"].shadow_blocked == fast["stats"].shadow_blocked, again
+        assert np.array_equal(r["rgb"], fast["rgb"])
+    scene.close()

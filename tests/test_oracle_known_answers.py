@@ -146,3 +146,44 @@ def test_sphere8_batches_keep_the_near_root_bug(oracle):
     # origin inside a sphere: the reference returns the near root, which is below the tolerance (often negative)
     inside = want[0::3][np.arange(len(want[0::3])), (np.arange(len(want))[0::3]) % 8]
     assert (inside < 1e-4).any()
+
+
+KA_ELL = np.load(os.path.join(ROOT, "tests", "golden", "known_answers_ellipsoid.npz"))
+
+
+def test_ellipsoid8_batches(oracle):
+    """The ellipsoid routines (ray_tracing.cpp:105-126, :208-263, :336-344) and the closest-hit body (:556-579), lane by lane."""
+    k = KA_ELL
+    n = len(k["o"])
+    got = {name: np.zeros_like(k[name]) for name in ("o2", "d2", "absent", "t2", "dist")}
+    for b in range(n):
+        inv8, fwd8 = np.ascontiguousarray(k["inv8"][b]), np.ascontiguousarray(k["fwd8"][b])
+        out = [np.zeros(24, np.float32), np.zeros(24, np.float32), np.zeros(8, np.float32), np.zeros(8, np.float32), np.zeros(8, np.float32)]
+        oracle.rto_ellipsoid8(C.byref(checkers.vec3(k["o"][b])), C.byref(checkers.vec3(k["d"][b])), inv8.ctypes.data, fwd8.ctypes.data, *[x.ctypes.data for x in out])
+        for name, v in zip(("o2", "d2", "absent", "t2", "dist"), out):
+            got[name][b] = v
+    for name in got:
+        assert same_bits(got[name], k[name]), name
+    flt_max = np.float32(np.finfo(np.float32).max)
+    assert (k["dist"] < flt_max).sum() > 100 and k["absent"].sum() > 100
+    # the signed absent test hides real ellipsoids (not only padding lanes) from rays whose mapped direction is all negative
+    real = np.abs(k["inv8"].reshape(n, 12, 8)).sum(axis=1) > 0
+    assert (k["absent"].astype(bool) & real).sum() > 50
+
+
+def test_ellipsoid_shadow_bodies(oracle):
+    """path_is_blocked (ray_tracing.cpp:347-458) on one ellipsoid at a time, point and directional lights."""
+    k = KA_ELL
+    n = len(k["shadow_start"])
+    blocked = np.zeros(n, np.float32)
+    dirs = np.zeros((n, 3), np.float32)
+    for i in range(n):
+        inv8 = np.zeros((12, 8), np.float32)
+        inv8[:, 0] = k["shadow_inv"][i]
+        out = (C.c_float * 3)()
+        blocked[i] = oracle.rto_ellipsoid8_blocks(C.byref(checkers.vec3(k["shadow_start"][i])), C.byref(checkers.vec3(k["shadow_light"][i])),
+                                                  int(k["shadow_point"][i]), inv8.ctypes.data, C.byref(out))
+        dirs[i] = list(out)
+    assert same_bits(dirs, k["shadow_dir"])
+    assert np.array_equal(blocked, k["shadow_blocked"])
+    assert 300 < blocked.sum() < n - 300
