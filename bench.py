@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--chunk-tiles", type=int, default=0, help="tiles per chunk of ray state (0 = library default)")
     ap.add_argument("--brute-force", action="store_true", help="time the frames themselves with RT_FLAG_NO_FILTER (slow: for small sizes)")
     ap.add_argument("--plain-test", action="store_true", help="brute-force scans use RT_FLAG_PLAIN_TEST: the triangle test exactly as written (three IEEE divisions per pair)")
+    ap.add_argument("--no-as-written", action="store_true", help="skip the part of the brute-force leg that runs the tests exactly as written on a quarter of the crop")
     ap.add_argument("--brute-crop", default="", help="centred crop of the brute-force leg (WxH)")
     ap.add_argument("--cpu-crop", default="", help="centred crop the CPU baseline renders (WxH)")
     return ap.parse_args()
@@ -88,7 +89,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    single_process = world == 1 and args.gpus > 1      # not under a launcher: one process drives all the GPUs (rt_init_devices / rt_render_multi)
+    # not under a launcher: one process drives all the GPUs (rt_init_devices / rt_render_multi_begin / _end); with one GPU that
+    # path is taken only when RT_AMD_COMM_ALWAYS is set (it then exchanges through RCCL all the same: a rehearsal of the N-GPU step)
+    single_process = world == 1 and (args.gpus > 1 or bool(os.environ.get("RT_AMD_COMM_ALWAYS")))
     if world != args.gpus and not single_process:
         args.gpus = world
 
@@ -284,7 +287,9 @@ def main():
         if not args.brute_force:
             out["output_ms"] = output_stage(api, scene, cam, prm, tiles[0], frame, fi, torch, world)
         if not args.no_brute_force_leg:
-            out["roofline"] = brute_force_leg(abi, fi, cam, scene, depth, args, label)
+            out["roofline"], out["brute_force"] = brute_force_leg(abi, fi, cam, scene, depth, args, label)
+            if args.brute_force:   # the timed frames themselves were brute force: the whole-frame figures beside the leg's
+                out["brute_force"]["timed_frames"] = {"mrays_s": out["value"], "ms_per_step": out["ms_per_step"], "tests_per_s": pairs / elapsed}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(api, abi, fi, cam, scene, depth, args.cpu_crop or CPU_CROP.get(args.workload, CPU_CROP["default"]))
         sys.stdout.flush()
@@ -299,7 +304,10 @@ def main():
 
 def single_process_bench(args, api, abi, results_fd):
     """--gpus N without a launcher: this one process drives N GPUs through the C ABI alone (rt_init_devices, rt_scene_create
-    replicating the scene, rt_render_multi: one host thread per device, RCCL gather to device 0, image copied to the host)."""
+    replicating the scene, rt_render_multi_begin / _end: one persistent host thread per device, RCCL gather to device 0).
+    A step is what a step of the launcher's path is: every device traces its share of frame k while the tiles of frame k - 1
+    travel and are scattered into the image, which stays in the memory of device 0; nothing is copied to the host."""
+    import torch
     n = args.gpus
     api.init_devices(n)
     fi, label, parse_s = load_workload(api, args.workload, args.width, args.height, args.maxdepth)
@@ -308,22 +316,45 @@ def single_process_bench(args, api, abi, results_fd):
     t0 = time.perf_counter()
     scene = api.Scene(fi.scene_desc)
     scene_create_s = time.perf_counter() - t0
-    prm = fi.params(max_bounce_count=depth)
-    for _ in range(args.warmup):
-        api.render_multi(scene, cam, prm, n)
+    prm = fi.params(max_bounce_count=depth, chunk_tiles=args.chunk_tiles)
+    images = [torch.zeros(fi.height * fi.width * 3, dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+    torch.cuda.synchronize()
+
+    def run(steps):
+        done, ticket = [], None
+        for k in range(steps):
+            now = api.render_multi_begin(scene, cam, prm, images[k % 2].data_ptr())
+            if ticket is not None:
+                done.append(api.render_multi_end(ticket, n))
+            ticket = now
+        if ticket is not None:
+            done.append(api.render_multi_end(ticket, n))
+        return done
+
+    run(args.warmup)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    frames = [api.render_multi(scene, cam, prm, n) for _ in range(args.steps)]      # each call returns with the image on the host
+    frames = run(args.steps)
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    rays = float(sum(st.closest_rays + st.shadow_rays for f in frames for st in f["stats"]))
-    per_device_ms = [sum(f["stats"][d].device_ms for f in frames) / args.steps for d in range(n)]
+    rays = float(sum(st.closest_rays + st.shadow_rays for stats, _ in frames for st in stats))
+    per_device_ms = [sum(stats[d].device_ms for stats, _ in frames) / args.steps for d in range(n)]
     out = {"metric": "Mrays/s", "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic" if args.workload == "synthetic" else "reference scene file (tests/golden/scenes), size overridden",
            "config": {"workload": label, "maxdepth": depth, "samples_per_pixel": 16, "parallelism": "tiles%%%d" % n,
-                      "exchange": "one process, rt_render_multi: RCCL grouped send/receive to device 0, image copied to the host inside every step"},
-           "per_device_ms": per_device_ms, "setup_ms": {"parse_scene_file": parse_s * 1e3, "scene_create_all_devices": scene_create_s * 1e3}}
-    alone = api.render_multi(scene, cam, fi.params(max_bounce_count=depth, rect_x0=0, rect_y0=0, rect_w=fi.width, rect_h=min(fi.height, 256)), n)
-    out["top_rows_identical_to_last_frame"] = bool((alone["rgb"] == frames[-1]["rgb"][:alone["rgb"].shape[0]]).all()) if frames else None
+                      "primitives": {"triangles": int(fi.scene_desc.n_triangles), "spheres": int(fi.scene_desc.n_spheres), "ellipsoids": int(fi.scene_desc.n_ellipsoids)},
+                      "lights": int(fi.scene_desc.n_point_lights) + int(fi.scene_desc.has_directional_light),
+                      "mode": "bounding hierarchy + conservative pre-tests, exact test on the survivors",
+                      "exchange": "one process, rt_render_multi_begin / _end: RCCL grouped send/receive to device 0 and scatter into the image on the exchange streams, "
+                                  "behind the next frame; image left in device memory" if n > 1 or os.environ.get("RT_AMD_COMM_ALWAYS") else "one device: no exchange, scatter into the image only"},
+           "rays_per_step": rays / max(args.steps, 1), "per_device_ms": per_device_ms,
+           "exchange_ms": sum(ms for _, ms in frames) / max(args.steps, 1),
+           "setup_ms": {"parse_scene_file": parse_s * 1e3, "scene_create_all_devices": scene_create_s * 1e3}}
+    # the frame the devices assembled in the last step against one rendered by device 0 alone (outside the timed steps)
+    alone = scene.render(cam, fi.params(max_bounce_count=depth))
+    last = images[(args.steps - 1) % 2].cpu().numpy() if args.steps else None
+    out["frame_identical_to_single_device_render"] = bool((alone["rgb"].reshape(-1) == last).all()) if last is not None else None
     scene.close()
     sys.stdout.flush()
     os.write(results_fd, (json.dumps(out) + "\n").encode())
@@ -355,10 +386,46 @@ def output_stage(api, scene, cam, prm, tiles, frame, fi, torch, world):
             "note": "PNG: Sub filter, zlib level 3 in up to 16 pieces on host threads; pixels identical to the framebuffer (tests/test_integration_binding.py)"}
 
 
+KINDS = ("triangle", "sphere", "ellipsoid")
+CLOSEST_KERNELS = {False: ("k_closest_tri_brute<1,true>", "k_closest_sph_eye<2> (rays from the eye) / k_closest_sph<2>", "k_closest_ell_staged<2>"),
+                   True: ("k_closest_tri_brute<1,false>", "k_closest_sph<2>", "k_closest_ell<2>")}
+SHADOW_KERNELS = {False: ("k_shadow_tri_brute<true>", "k_shadow_brute<2,2>", "k_shadow_brute<2,1>"),
+                  True: ("k_shadow_tri_brute<false>", "k_shadow_sph<2>", "k_shadow_ell<2>")}
+
+
+def kernel_table(st, fi, plain):
+    """Per primitive kind and scan: counted ray-primitive pairs, HIP-event time of the launches, reference-equivalent FLOP
+    (pairs x the FLOP of the reference's test with the ray-independent parts hoisted: 54 / 19 / 95, shadow ellipsoid 71 toward
+    a point light and 62 toward the directional one, weighted by the number of lights of each sort) and the share of the FP32 peak."""
+    n_point, n_dir = int(fi.scene_desc.n_point_lights), int(fi.scene_desc.has_directional_light)
+    ell_shadow = (FLOP_ELL_SHADOW_POINT * n_point + FLOP_ELL_SHADOW_DIR * n_dir) / max(n_point + n_dir, 1)
+    flop = {"closest": (FLOP_TRI, FLOP_SPH, FLOP_ELL_CLOSEST), "shadow": (FLOP_TRI, FLOP_SPH, ell_shadow)}
+    rows, total_flop, total_ms, total_pairs = {}, 0.0, 0.0, 0.0
+    for scan, pairs_of, ms_of, launches_of, names in (("closest", st.closest_tests, st.closest_kind_ms, st.closest_kind_launches, CLOSEST_KERNELS[plain]),
+                                                       ("shadow", st.shadow_tests, st.shadow_kind_ms, st.shadow_kind_launches, SHADOW_KERNELS[plain])):
+        for k, kind in enumerate(KINDS):
+            pairs, ms, launches = float(pairs_of[k]), float(ms_of[k]), int(launches_of[k])
+            if launches == 0:
+                continue
+            tflops = pairs * flop[scan][k] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            rows["%s_%s" % (scan, kind)] = {
+                "kernel": names[k], "pairs": pairs, "flop_per_pair": flop[scan][k], "ms": ms, "launches": launches, "avg_launch_ms": ms / launches,
+                "flop_per_launch": pairs * flop[scan][k] / launches, "pairs_per_s": pairs / (ms * 1e-3) if ms > 0 else 0.0,
+                "achieved": tflops, "frac": tflops / PEAK_FP32_TFLOPS}
+            total_flop += pairs * flop[scan][k]
+            total_ms += ms
+            total_pairs += pairs
+    tflops = total_flop / (total_ms * 1e-3) / 1e12 if total_ms > 0 else 0.0
+    total = {"what": "sum over kinds and scans of pairs x FLOP of the kind / sum of the scans' kernel seconds", "pairs": total_pairs, "flop": total_flop, "kernel_ms": total_ms,
+             "pairs_per_s": total_pairs / (total_ms * 1e-3) if total_ms > 0 else 0.0, "achieved": tflops, "frac": tflops / PEAK_FP32_TFLOPS}
+    return rows, total
+
+
 def brute_force_leg(abi, fi, cam, scene, depth, args, label):
     """Every ray against every primitive (RT_FLAG_NO_FILTER) on a centred crop of the same frame; one chunk, one stream,
     launches one after the other, each between two HIP events on the stream it is launched on (rt_stats.*_kind_ms).
-    The dominant kernels are the brute-force triangle scans: closest hit (k_closest_tri_brute) and shadow (k_shadow_tri_brute)."""
+    Returns the `roofline` object (headed by the closest-hit scan of the kind that takes the most closest-hit time, with every
+    kind's closest-hit and shadow scan and their sum beside it) and the `brute_force` summary."""
     crop = args.brute_crop or BRUTE_CROP.get(args.workload, BRUTE_CROP["default"])
     rect, cw, ch = centred(fi, crop)
     flags = abi.RT_FLAG_NO_FILTER | (abi.RT_FLAG_PLAIN_TEST if args.plain_test else 0)
@@ -366,43 +433,58 @@ def brute_force_leg(abi, fi, cam, scene, depth, args, label):
     brute = scene.render(cam, prm)
     fast = scene.render(cam, fi.params(max_bounce_count=depth, **rect))
     st = brute["stats"]
-    n_tri = int(fi.scene_desc.n_triangles)
-
-    def kernel(name, pairs, ms, launches):
-        tflops = pairs * FLOP_TRI / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        return {"kernel": name, "achieved": tflops, "frac": tflops / PEAK_FP32_TFLOPS, "pairs": pairs, "pairs_per_s": pairs / (ms * 1e-3) if ms > 0 else 0.0,
-                "launches": int(launches), "avg_launch_ms": ms / max(launches, 1), "flop_per_launch": pairs * FLOP_TRI / max(launches, 1)}
-
-    variant = "false" if args.plain_test else "true"
-    closest = kernel("k_closest_tri_brute<1,%s>" % variant, float(st.closest_tests[0]), st.closest_kind_ms[0], st.closest_kind_launches[0])
-    shadow = kernel("k_shadow_tri_brute<%s>" % variant, float(st.shadow_tests[0]), st.shadow_kind_ms[0], st.shadow_kind_launches[0])
-    measured = profile_figures(label, args.plain_test)
+    rows, total = kernel_table(st, fi, args.plain_test)
+    closest_rows = {k: v for k, v in rows.items() if k.startswith("closest_")}
+    head_name = max(closest_rows, key=lambda k: closest_rows[k]["ms"]) if closest_rows else None
+    head = dict(rows[head_name]) if head_name else {"kernel": None, "achieved": 0.0, "frac": 0.0}
+    measured = profile_figures(label, args.plain_test) if head_name == "closest_triangle" else {}
     out = {"bound": "valu_fp32", "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s"}
-    out.update(closest)
+    out.update(head)
     out.update({
         "traffic": measured.get("closest_hbm_bytes_per_launch"),
         "valu_issue_utilisation": measured.get("closest_valu_issue_utilisation"),
-        "what": "ray-triangle pairs x 54 FLOP of the reference's test / HIP-event time of the launches; every pair is visited, the test is evaluated in "
-                "stages that skip what the outcome does not depend on (results identical to the test as written, which --plain-test runs)",
-        "sample": "centred %dx%d-pixel crop of %s, maxdepth %d: %d closest-hit rays, %d shadow rays, %d triangles" % (cw, ch, label, depth, st.closest_rays, st.shadow_rays, n_tri),
-        "shadow_kernel": dict(shadow, traffic=measured.get("shadow_hbm_bytes_per_launch"), valu_issue_utilisation=measured.get("shadow_valu_issue_utilisation"),
-                              pairs_counted="triangles staged while the ray was still open (a ray joins the list at the tile its workgroup has reached, goes once round and leaves at the first "
-                                            "refill after it is blocked)"),
-        "dominant_by_time": "k_shadow_tri_brute" if st.shadow_kind_ms[0] > st.closest_kind_ms[0] else "k_closest_tri_brute",
-        "other_kinds_ms": {"closest_sphere": st.closest_kind_ms[1], "closest_ellipsoid": st.closest_kind_ms[2], "shadow_sphere": st.shadow_kind_ms[1], "shadow_ellipsoid": st.shadow_kind_ms[2]},
+        "traffic_source": (measured.get("source") or "profiles/traffic.json") + ": rocprofv3 PMC passes of this command run by the builder; copied, not measured in this run" if measured else None,
+        "flop_basis": "reference-equivalent: counted pairs x FLOP of the reference's test (ray-independent parts hoisted). Every pair is visited; the "
+                      + ("test is evaluated as written" if args.plain_test else
+                         "test is evaluated in stages that skip what the outcome does not depend on, so fewer operations are executed per pair than "
+                         "are credited (results identical to the test as written; `as_written` below is that form's figure)"),
+        "sample": "centred %dx%d-pixel crop of %s, maxdepth %d: %d closest-hit rays, %d shadow rays" % (cw, ch, label, depth, st.closest_rays, st.shadow_rays),
+        "kernels": rows,
+        "all_kinds": total,
+        "dominant_by_time": max(rows, key=lambda k: rows[k]["ms"]) if rows else None,
+        "shadow_pairs_counted": "primitives staged while the ray was still open (triangle scan: a ray joins the list at the tile its workgroup has reached, goes once "
+                                "round and leaves at the first refill after it is blocked)",
         "leg_device_ms": st.device_ms,
         "image_identical_to_default_mode": bool((brute["rgb"] == fast["rgb"]).all()),
         "counters_identical_to_default_mode": all(getattr(st, f) == getattr(fast["stats"], f) for f in ("closest_rays", "hits", "shadow_rays", "shadow_blocked")),
     })
-    return out
+    if "shadow_triangle" in rows:
+        out["shadow_kernel"] = dict(rows["shadow_triangle"], traffic=measured.get("shadow_hbm_bytes_per_launch"), valu_issue_utilisation=measured.get("shadow_valu_issue_utilisation"))
+    if not args.plain_test and not args.no_as_written:
+        # the same scans with every test evaluated exactly as written, on a quarter of the crop (they take three to five times as long)
+        small, sw, sh = centred(fi, "%dx%d" % (max(cw // 2, 16), max(ch // 2, 16)))
+        plain = scene.render(cam, fi.params(max_bounce_count=depth, flags=abi.RT_FLAG_NO_FILTER | abi.RT_FLAG_PLAIN_TEST, **small))
+        staged = scene.render(cam, fi.params(max_bounce_count=depth, flags=abi.RT_FLAG_NO_FILTER, **small))
+        plain_rows, plain_total = kernel_table(plain["stats"], fi, True)
+        out["as_written"] = {"sample": "centred %dx%d-pixel crop" % (sw, sh), "frac": {k: v["frac"] for k, v in plain_rows.items()}, "all_kinds_frac": plain_total["frac"],
+                             "kernel_ms": plain_total["kernel_ms"], "image_identical_to_staged": bool((plain["rgb"] == staged["rgb"]).all())}
+    rays = float(st.closest_rays + st.shadow_rays)
+    summary = {"what": "RT_FLAG_NO_FILTER: every ray against every primitive, the mode BASELINE's largest configuration names; " + out["sample"],
+               "mrays_s": rays / (st.device_ms * 1e-3) / 1e6 if st.device_ms > 0 else 0.0, "tests_per_s": total["pairs_per_s"],
+               "frac_of_fp32_peak": total["frac"], "device_ms": st.device_ms, "rays": rays, "pairs": total["pairs"]}
+    return out, summary
 
 
 def profile_figures(label, plain):
-    """Figures of the brute-force kernels from the committed rocprofv3 PMC passes (profiles/traffic.json), or {}."""
+    """Figures of the brute-force triangle scans from the committed rocprofv3 PMC passes (profiles/traffic.json), or {}."""
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         got = table.get(label + ("/brute-force-plain" if plain else "/brute-force"))
-        return got if isinstance(got, dict) else {}
+        if not isinstance(got, dict):
+            return {}
+        got = dict(got)
+        got.setdefault("source", table.get("source"))
+        return got
     except (OSError, ValueError):
         return {}
 
@@ -410,9 +492,11 @@ def profile_figures(label, plain):
 def cpu_baseline(api, abi, fi, cam, scene, depth, crop):
     """Time the CPU renderer on a centred crop of the same frame, on this box's host cores.
 
-    The unmodified reference (oracle/_ref/librt_ref.so, multithreaded over scanlines like its
-    work queue) when that library is present, else the scalar restatement in oracle/.  Ray counts
-    for the crop come from the GPU path, whose counters are identical to the oracle's.
+    The unmodified reference (oracle/_ref/librt_ref.so) when that library is present, else the scalar restatement in
+    oracle/.  As many workers as this process has hardware threads (the reference starts hardware_concurrency() of them,
+    Source/main.cpp:77-83), fed from one atomic counter like the reference's queue (Source/render_work_queue.cpp:59-80) with
+    segments of four pixels, so that the workers finish together.  Ray counts for the crop come from the GPU path, whose
+    counters are identical to the oracle's.
     """
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import checkers
@@ -420,16 +504,21 @@ def cpu_baseline(api, abi, fi, cam, scene, depth, crop):
     prm = fi.params(max_bounce_count=depth, **rect)
     g = scene.render(cam, prm)
     rays = g["stats"].closest_rays + g["stats"].shadow_rays
-    threads = min(os.cpu_count() or 1, 16)
+    pairs = float(sum(g["stats"].closest_tests[k] for k in range(3)))     # closest-hit pairs; the CPU's shadow scans stop at the first blocker and are not counted here
+    threads = checkers.available_cpus()
     if checkers.have_ref():
         lib, prefix, kind = checkers.load_ref(), "ref_", "reference"
     else:
         lib, prefix, kind = checkers.load_oracle(), "rto_", "port"
     r = checkers.cpu_render(lib, prefix, fi.scene_desc, cam, prm, threads=threads)
     same = bool((r["rgb"] == g["rgb"]).all())
-    return {"value": rays / r["seconds"] / 1e6, "unit": "Mrays/s", "cores": threads, "kind": kind, "cpu_model": cpu_model(),
+    busy = r["worker_seconds"]
+    return {"value": rays / r["seconds"] / 1e6, "unit": "Mrays/s", "cores": threads, "cores_available": threads, "threads_used": threads,
+            "cpu_count_reported_by_os": os.cpu_count(), "kind": kind, "cpu_model": cpu_model(),
             "sample": "centred %dx%d-pixel crop of the same frame (%d rays), %.1f s" % (cw, ch, rays, r["seconds"]),
-            "seconds": r["seconds"], "image_identical_to_gpu": same}
+            "seconds": r["seconds"], "closest_hit_tests_per_s": pairs / r["seconds"],
+            "worker_seconds_min_max": [float(busy.min()), float(busy.max())], "workers_finish_within": float(1.0 - busy.min() / busy.max()) if busy.max() > 0 else None,
+            "image_identical_to_gpu": same}
 
 
 def cpu_model():

@@ -150,9 +150,11 @@ typedef struct rt_stats {
                                        depth-first walk a step serves either the lanes that hold a node or those that hold a leaf */
 } rt_stats;
 
-/* Thread safety: the library renders on one GPU per process with one set of streams and ray-state arenas; rt_scene_create,
- * the render calls and rt_assemble_tiles_device take a library lock, so concurrent calls are safe and run one after the other
- * (the reference's render_scanline is re-entrant; parallelism here is inside a call). */
+/* Thread safety: a GPU has one set of streams and ray-state arenas per frame slot; rt_scene_create, the render calls,
+ * rt_render_tiles_begin / _end, rt_render_multi_begin / _end and rt_assemble_tiles_device take locks of the library, so
+ * concurrent calls from any threads are safe and run one after the other (the reference's render_scanline is re-entrant;
+ * parallelism here is inside a call).  Bounding records that have to be rebuilt for a camera far outside the scene are
+ * rebuilt when no frame that reads them is in flight.  A frame begun and never ended is completed when the library is unloaded. */
 typedef struct rt_scene rt_scene;          /* opaque: device-resident scene */
 typedef struct rt_file_info rt_file_info;  /* opaque: a parsed .test file */
 
@@ -191,8 +193,10 @@ int rt_render_tiles_device(const rt_scene* scene, const rt_camera_desc* camera, 
  * (one rank's share of a split frame).  tiles_dev must stay valid until end; the frames' results do not depend on each other. */
 int rt_render_tiles_begin(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params, void* tiles_dev, int* ticket);
 int rt_render_tiles_end(int ticket, rt_stats* stats);
-/* rt_render_tiles_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
- * harnesses that forbid it); it has no counterpart in the reference.  The call allocates, creates and frees nothing:
+/* rt_render_tiles_device for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc, code that
+ * runs between the captures of HIP graphs); it has no counterpart in the reference.  The call allocates, creates and frees nothing,
+ * but it does synchronise: it launches on the library's own streams, reads the ray count back after every bounce and
+ * returns with those streams idle, so it cannot itself be captured into a HIP graph.
  * the per-sample state lives in a fixed device array of the library (about 37 MB per GPU, held until the process ends),
  * so this rank's share of the rectangle may be at most RT_NOALLOC_MAX_TILES tiles (e.g. 128x128 pixels); a larger one is
  * refused with an error.  Same tile buffer, same bytes as rt_render_tiles_device; no statistics.  Every call on a GPU
@@ -214,9 +218,15 @@ int rt_assemble_tiles_device(const void* gathered_tiles_dev, uint32_t tiles_per_
  * Here tile t of the rectangle belongs to GPU t % n, the scene is replicated, and the only exchange is every GPU sending
  * its compact tile buffer to the first one over xGMI (RCCL, grouped send / receive), which scatters them into the image.
  * Two ways to set it up:
- *  (1) ONE PROCESS, n GPUs: rt_init_devices(n) (devices 0..n-1, one host thread and one set of streams per device, one
- *      RCCL communicator from ncclCommInitAll); rt_scene_create then replicates the scene on every device, and
- *      rt_render_multi stands where rt_render does: same image bytes.  stats_per_device: n entries, or null.
+ *  (1) ONE PROCESS, n GPUs: rt_init_devices(n) (devices 0..n-1, one host thread and one set of streams per device, started
+ *      once and kept, as the reference starts its workers once, Source/main.cpp:77-90; one RCCL communicator from
+ *      ncclCommInitAll); rt_scene_create then replicates the scene on every device, and rt_render_multi stands where
+ *      rt_render does: same image bytes.  stats_per_device: n entries, or null.
+ *      rt_render_multi_begin / rt_render_multi_end are the same frame in two halves with the image left in memory of
+ *      device 0 (rgb_dev: rect_w x rect_h RGB8): begin returns when every device has traced its share and the exchange
+ *      (gather to device 0 + scatter into rgb_dev) is enqueued; end waits for that exchange and returns the per-device
+ *      statistics (if begin was given want_stats) and the device time of the exchange.  Up to two frames may be under way,
+ *      so that the tiles of frame k travel while frame k + 1 is traced: begin(k + 1); end(k); begin(k + 2); ...
  *  (2) ONE PROCESS PER GPU (rank r renders with tile_rank = r, tile_world = n): rank 0 calls rt_comm_unique_id and hands
  *      the identifier to the others by any means the host has; every rank calls rt_comm_init_rank after rt_init;
  *      after rt_render_tiles_device has returned, rt_comm_gather_tiles enqueues the exchange of the tile buffers on a
@@ -226,6 +236,9 @@ int rt_assemble_tiles_device(const void* gathered_tiles_dev, uint32_t tiles_per_
 int rt_init_devices(int n_devices);
 int rt_render_multi(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params,
                     uint8_t* rgb_out, rt_stats* stats_per_device);
+int rt_render_multi_begin(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params,
+                          void* rgb_dev, int want_stats, int* ticket);
+int rt_render_multi_end(int ticket, rt_stats* stats_per_device, double* exchange_ms);
 int rt_comm_unique_id(uint8_t id[RT_COMM_ID_BYTES]);
 int rt_comm_init_rank(const uint8_t id[RT_COMM_ID_BYTES], int rank, int world);
 int rt_comm_gather_tiles(const void* tiles_dev, uint32_t tiles_per_rank_stride, void* gathered_dev);

@@ -13,6 +13,7 @@
 // Win32 profiler out, and defines TIME_BLOCK as the empty macro the reference
 // itself uses whenever PROFILING is off (Source/profiling.cpp:131-135).
 // FLT_MAX, which the reference picks up through <Windows.h>, comes from <cfloat>.
+#include <algorithm>
 #include <atomic>
 #include <cfloat>
 #include <chrono>
@@ -246,8 +247,17 @@ void ref_trace(const rt_scene_desc* desc, const float o[3], const float d[3], in
 
 // ---- render --------------------------------------------------------------------
 // rgb: rect_w*rect_h*3; ids (nullable): rect_w*rect_h*16; sample_colours (nullable): rect_w*rect_h*16*3.
-// Rows are handed to n_threads workers one at a time through an atomic counter,
-// each row rendered by the reference's render_scanline into a full-width image.
+// Work is handed to n_threads workers through an atomic counter, like the reference's queue
+// (Source/render_work_queue.cpp:59-80): whole rows, each rendered by the reference's render_scanline into a
+// full-width image, when the rectangle spans the image's width; otherwise segments of SEGMENT pixels of a row
+// (a crop has few rows: whole rows would leave most workers idle in the last round).
+// The seconds each worker spent in its loop are kept for ref_worker_seconds.
+namespace { std::vector<double> g_worker_seconds; }
+int ref_worker_seconds(double* out, int n) {
+    const int have = static_cast<int>(g_worker_seconds.size());
+    for (int i = 0; i < n && i < have; ++i) out[i] = g_worker_seconds[static_cast<std::size_t>(i)];
+    return have;
+}
 int ref_render(const rt_scene_desc* desc, const rt_camera_desc* cam, const rt_render_params* prm,
                uint8_t* rgb, uint32_t* ids, float* sample_colours, int n_threads, double* render_seconds) {
     const Scene scene = scene_from_desc(*desc);
@@ -268,11 +278,18 @@ int ref_render(const rt_scene_desc* desc, const rt_camera_desc* cam, const rt_re
     if (whole_rows) full.resize(static_cast<std::size_t>(W) * H * 3);
     Image image{W, H, full.data(), ""};
 
+    constexpr unsigned SEGMENT = 4;
+    const unsigned segments = whole_rows ? 1u : (rw + SEGMENT - 1) / SEGMENT;
+    const unsigned units = rh * segments;
     std::atomic<unsigned> next{0};
-    auto worker = [&]() {
+    g_worker_seconds.assign(static_cast<std::size_t>(n_threads < 1 ? 1 : n_threads), 0.0);
+    auto worker = [&](int tid) {
+        const auto began = std::chrono::steady_clock::now();
         for (;;) {
-            const unsigned r = next.fetch_add(1);
-            if (r >= rh) break;
+            const unsigned u = next.fetch_add(1);
+            if (u >= units) break;
+            const unsigned r = u / segments;
+            const unsigned xa = whole_rows ? x0 : x0 + (u % segments) * SEGMENT, xb = whole_rows ? x0 + rw : std::min(x0 + rw, xa + SEGMENT);
             const unsigned y = y0 + r;
             if (whole_rows) {
                 render_scanline(scene, camera, basis, image, half_world, y, prm->max_bounce_count);
@@ -280,7 +297,7 @@ int ref_render(const rt_scene_desc* desc, const rt_camera_desc* cam, const rt_re
             }
             if (!whole_rows || ids || sample_colours) {
                 // per-sample walk with the reference's own functions, in render_scanline's order (render_work_queue.cpp:37-56)
-                for (unsigned x = x0; x < x0 + rw; ++x) {
+                for (unsigned x = xa; x < xb; ++x) {
                     Colour colour{0.0f, 0.0f, 0.0f};
                     for (int sample = 0; sample < 16; ++sample) {
                         const float xo = static_cast<float>(sample % 4) * 0.25f + 2.0f;
@@ -315,11 +332,12 @@ int ref_render(const rt_scene_desc* desc, const rt_camera_desc* cam, const rt_re
                 }
             }
         }
+        g_worker_seconds[static_cast<std::size_t>(tid)] = std::chrono::duration<double>(std::chrono::steady_clock::now() - began).count();
     };
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> threads;
-    for (int t = 1; t < n_threads; ++t) threads.emplace_back(worker);
-    worker();
+    for (int t = 1; t < n_threads; ++t) threads.emplace_back(worker, t);
+    worker(0);
     for (auto& t : threads) t.join();
     if (render_seconds) *render_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return 0;

@@ -509,7 +509,13 @@ void rto_camera_setup(const float cam[11], rt_camera_desc* out) {
     out->half_world[1] = tanf(0.5f * (cam[10] / 180.0f * PI));
 }
 
-// Same contract as ref_render in ref_harness.cpp, plus exact counters.
+namespace { std::vector<double> g_worker_seconds; }
+int rto_worker_seconds(double* out, int n) {
+    const int have = static_cast<int>(g_worker_seconds.size());
+    for (int i = 0; i < n && i < have; ++i) out[i] = g_worker_seconds[static_cast<size_t>(i)];
+    return have;
+}
+// Same contract as ref_render in ref_harness.cpp (work units: segments of 4 pixels of a row), plus exact counters.
 int rto_render(const rt_scene_desc* desc, const rt_camera_desc* cam, const rt_render_params* prm,
                uint8_t* rgb, uint32_t* ids, float* sample_colours, int n_threads, rt_stats* stats, double* render_seconds) {
     const SceneView sv{desc};
@@ -521,15 +527,20 @@ int rto_render(const rt_scene_desc* desc, const rt_camera_desc* cam, const rt_re
     const uint32_t tile_world = prm->tile_world ? prm->tile_world : 1;
     const uint32_t tiles_x = (rw + RT_TILE - 1) / RT_TILE;
 
+    constexpr unsigned SEGMENT = 4;
+    const unsigned segments = (rw + SEGMENT - 1) / SEGMENT, units = rh * segments;
     std::atomic<unsigned> next{0};
     std::vector<Counters> per_thread(static_cast<size_t>(n_threads < 1 ? 1 : n_threads));
+    g_worker_seconds.assign(per_thread.size(), 0.0);
     auto worker = [&](int tid) {
         Counters& cn = per_thread[static_cast<size_t>(tid)];
+        const auto began = std::chrono::steady_clock::now();
         for (;;) {
-            const unsigned r = next.fetch_add(1);
-            if (r >= rh) break;
+            const unsigned u = next.fetch_add(1);
+            if (u >= units) break;
+            const unsigned r = u / segments;
             const unsigned y = y0 + r;
-            for (unsigned xr = 0; xr < rw; ++xr) {
+            for (unsigned xr = (u % segments) * SEGMENT; xr < rw && xr < (u % segments + 1) * SEGMENT; ++xr) {
                 // the tile numbering of the library (include/rt_amd.h): rows of tiles rotated against each other
                 const uint32_t tile_row = r / RT_TILE, place = (xr / RT_TILE + tile_row % tiles_x) % tiles_x;
                 const uint32_t tile = tile_row * tiles_x + place;
@@ -561,6 +572,7 @@ int rto_render(const rt_scene_desc* desc, const rt_camera_desc* cam, const rt_re
                 }
             }
         }
+        g_worker_seconds[static_cast<size_t>(tid)] = std::chrono::duration<double>(std::chrono::steady_clock::now() - began).count();
     };
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> threads;

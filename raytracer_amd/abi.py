@@ -125,6 +125,8 @@ PROTOTYPES = {
     "rt_assemble_tiles_device": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(RenderParams), C.c_void_p]),
     "rt_init_devices": (C.c_int, [C.c_int]),
     "rt_render_multi": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]),
+    "rt_render_multi_begin": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "rt_render_multi_end": (C.c_int, [C.c_int, C.POINTER(Stats), C.POINTER(C.c_double)]),
     "rt_comm_unique_id": (C.c_int, [C.c_void_p]),
     "rt_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rt_comm_gather_tiles": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),

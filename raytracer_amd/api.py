@@ -174,6 +174,21 @@ def render_multi(scene, camera, params, n_devices):
     return {"rgb": rgb, "stats": list(stats)}
 
 
+def render_multi_begin(scene, camera, params, rgb_dev_ptr, want_stats=True):
+    """rt_render_multi_begin: every device traces its share, the exchange into rgb_dev (memory of device 0) is enqueued; returns the ticket."""
+    ticket = C.c_int(-1)
+    _check(lib().rt_render_multi_begin(scene._h, C.byref(camera), C.byref(params), C.c_void_p(rgb_dev_ptr), 1 if want_stats else 0, C.byref(ticket)))
+    return ticket.value
+
+
+def render_multi_end(ticket, n_devices):
+    """rt_render_multi_end: waits for the frame's exchange; returns (per-device statistics, device milliseconds of gather + assembly)."""
+    stats = (abi.Stats * n_devices)()
+    exchange_ms = C.c_double(0.0)
+    _check(lib().rt_render_multi_end(int(ticket), stats, C.byref(exchange_ms)))
+    return list(stats), exchange_ms.value
+
+
 def comm_unique_id():
     buf = (C.c_uint8 * 128)()
     _check(lib().rt_comm_unique_id(buf))

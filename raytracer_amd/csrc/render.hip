@@ -33,6 +33,8 @@
 #include <atomic>
 
 #include <cfloat>
+#include <condition_variable>
+#include <functional>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -3604,10 +3606,14 @@ struct Library {
     int comm_rank = 0, comm_world = 1;
     hipStream_t comm_stream = nullptr;
     hipEvent_t comm_ready = nullptr;        // the tiles to send are complete
-    uint8_t* multi_tiles = nullptr;         // rt_render_multi: this device's tile buffer, and on device 0 the gathered buffers and the image
-    uint8_t* multi_gathered = nullptr;
+    // rt_render_multi*: this device's tile buffers (two frames may be under way: one being traced, one being exchanged), an
+    // event per buffer that says its exchange is complete, and on device 0 the gathered buffers and rt_render_multi's image
+    uint8_t* multi_tiles[2] = {nullptr, nullptr};
+    uint8_t* multi_gathered[2] = {nullptr, nullptr};
     uint8_t* multi_image = nullptr;
-    size_t multi_tiles_bytes = 0, multi_gathered_bytes = 0, multi_image_bytes = 0;
+    size_t multi_tiles_bytes[2] = {0, 0}, multi_gathered_bytes[2] = {0, 0}, multi_image_bytes = 0;
+    hipEvent_t multi_sent[2] = {nullptr, nullptr};
+    hipEvent_t multi_exchange_begin[2] = {nullptr, nullptr}, multi_exchange_end[2] = {nullptr, nullptr};   // device 0: around gather + assembly (timed)
 };
 // One context per HIP device.  A process that renders on one GPU (rt_init) has one; rt_init_devices creates one per
 // device of a single process.  Calls use the context their thread was bound to (bind_device), or the first one created.
@@ -4509,6 +4515,11 @@ static int init_device(int device) {
     lib.stream = lib.slots[0].lanes[0].stream;
     HIP_TRY(hipStreamCreateWithFlags(&lib.comm_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&lib.comm_ready, hipEventDisableTiming));
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipEventCreateWithFlags(&lib.multi_sent[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreate(&lib.multi_exchange_begin[k]));
+        HIP_TRY(hipEventCreate(&lib.multi_exchange_end[k]));
+    }
     // this device's copy of the scratch array of rt_render_tiles_noalloc: its address, once, with the device current
     HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&lib.scratch), HIP_SYMBOL(scratch)));
     if (!lib.scratch) return rt_fail(RT_ERR_DEVICE, "rt_init: the scratch array has no device address");
@@ -4951,6 +4962,74 @@ int grow(uint8_t** buffer, size_t* have, size_t need) {
     return 0;
 }
 
+// One host thread per device, started by rt_init_devices and kept until the library is unloaded (the reference starts its
+// workers once and joins them once, Source/main.cpp:77-90): a frame hands every device its share and waits for all of them.
+struct DeviceWorker {
+    std::thread thread;
+    std::mutex guard;
+    std::condition_variable wake;
+    std::function<void()> job;
+    bool has_job = false, stop = false;
+};
+struct WorkerPool {
+    DeviceWorker workers[MAX_DEVICES];
+    int n = 0;
+    void start(int count) {
+        for (int d = n; d < count; ++d) {
+            DeviceWorker& w = workers[d];
+            w.thread = std::thread([&w, d] {
+                DeviceBinding bound(g_devices[d]);
+                for (;;) {
+                    std::function<void()> job;
+                    {
+                        std::unique_lock<std::mutex> lock(w.guard);
+                        w.wake.wait(lock, [&w] { return w.has_job || w.stop; });
+                        if (w.stop) return;
+                        job = std::move(w.job);
+                    }
+                    job();
+                    {
+                        std::lock_guard<std::mutex> lock(w.guard);
+                        w.has_job = false;
+                    }
+                    w.wake.notify_all();
+                }
+            });
+        }
+        n = std::max(n, count);
+    }
+    // runs body(d) on the thread of every device d < count and returns when all are done
+    template <typename Body>
+    void on_every_device(int count, Body&& body) {
+        for (int d = 0; d < count; ++d) {
+            DeviceWorker& w = workers[d];
+            {
+                std::lock_guard<std::mutex> lock(w.guard);
+                w.job = [&body, d] { body(d); };
+                w.has_job = true;
+            }
+            w.wake.notify_all();
+        }
+        for (int d = 0; d < count; ++d) {
+            DeviceWorker& w = workers[d];
+            std::unique_lock<std::mutex> lock(w.guard);
+            w.wake.wait(lock, [&w] { return !w.has_job; });
+        }
+    }
+    ~WorkerPool() {
+        for (int d = 0; d < n; ++d) {
+            { std::lock_guard<std::mutex> lock(workers[d].guard); workers[d].stop = true; }
+            workers[d].wake.notify_all();
+            if (workers[d].thread.joinable()) workers[d].thread.join();
+        }
+    }
+};
+WorkerPool g_pool;          // (after g_devices: destroyed before the device contexts)
+std::mutex g_multi_guard;   // one rt_render_multi_begin / _end at a time
+struct MultiFrame { bool busy = false; int n = 0; rt_stats stats[MAX_DEVICES]; bool timed = false; };
+MultiFrame g_multi_frames[2];
+int g_multi_next = 0;       // the buffer set the next frame takes
+
 }  // namespace
 
 extern "C" {
@@ -5025,68 +5104,112 @@ int rt_init_devices(int n_devices) {
         for (int d = 0; d < n_devices; ++d) { g_devices[d].comm = comms[d]; g_devices[d].comm_rank = d; g_devices[d].comm_world = n_devices; }
         HIP_TRY(hipSetDevice(0));
     }
+    g_pool.start(n_devices);
     g_multi_devices.store(n_devices);
     return 0;
+}
+
+
+// A frame over all devices in two halves, with the result left in device memory.  begin: every device traces its share into
+// a tile buffer of its own (one host thread per device; returns when all shares are complete) and the exchange is enqueued
+// on the exchange streams - every device sends its buffer to device 0 (RCCL, grouped send / receive), which scatters the
+// tiles into rgb_dev (memory of device 0, rect_w x rect_h RGB8).  end: waits for that exchange.  Two frames may be under
+// way, so that the tiles of frame k travel while frame k + 1 is traced:  begin(k + 1); end(k); begin(k + 2); ...
+int rt_render_multi_begin(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params, void* rgb_dev, int want_stats, int* ticket) {
+    const int n = g_multi_devices.load();
+    if (n < 1) return rt_fail(RT_ERR_DEVICE, "rt_render_multi: rt_init_devices has not been called");
+    if (!scene || !camera || !params || !rgb_dev || !ticket) return rt_fail(RT_ERR_ARGUMENT, "rt_render_multi: null argument");
+    return guarded([&]() -> int {
+        std::lock_guard<std::mutex> one_at_a_time(g_multi_guard);
+        const int set = g_multi_next;
+        MultiFrame& frame = g_multi_frames[set];
+        if (frame.busy) return rt_fail(RT_ERR_LIMIT, "rt_render_multi_begin: two frames are under way already (rt_render_multi_end)");
+        const Rect rect = rect_of(*params);
+        if (rect.w == 0 || rect.h == 0) return rt_fail(RT_ERR_ARGUMENT, "rt_render_multi: empty rectangle");
+        const uint32_t stride = ceil_div(rect.tiles, static_cast<uint32_t>(n));
+        const size_t bytes = static_cast<size_t>(stride) * 768;
+        int rc_of[MAX_DEVICES] = {};
+        std::string error_of[MAX_DEVICES];
+        g_pool.on_every_device(n, [&](int d) {
+            Library& lib = g_devices[d];
+            int rc = grow(&lib.multi_tiles[set], &lib.multi_tiles_bytes[set], bytes);
+            if (!rc && d == 0) rc = grow(&lib.multi_gathered[set], &lib.multi_gathered_bytes[set], bytes * n);
+            if (!rc) {
+                rt_render_params mine = *params;
+                mine.tile_rank = static_cast<uint32_t>(d);
+                mine.tile_world = static_cast<uint32_t>(n);
+                rc = guarded([&] { return render_impl(scene, camera, &mine, lib.multi_tiles[set], nullptr, want_stats ? &frame.stats[d] : nullptr); });   // returns with the device's streams idle
+            }
+            rc_of[d] = rc;
+            if (rc) error_of[d] = g_last_error;
+        });
+        for (int d = 0; d < n; ++d) if (rc_of[d]) return rt_fail(rc_of[d], error_of[d].c_str());
+        Library& root = g_devices[0];
+        DeviceBinding bound(root);
+        HIP_TRY(hipEventRecord(root.multi_exchange_begin[set], root.comm_stream));
+        const uint8_t* gathered = root.multi_tiles[set];
+        if (root.comm) {
+            Library* devices[MAX_DEVICES];
+            const uint8_t* send[MAX_DEVICES];
+            for (int d = 0; d < n; ++d) { devices[d] = &g_devices[d]; send[d] = g_devices[d].multi_tiles[set]; }
+            if (int rc = enqueue_gather(devices, send, n, bytes, root.multi_gathered[set])) return rc;
+            gathered = root.multi_gathered[set];
+        }
+        hipLaunchKernelGGL(k_assemble, dim3(ceil_div(rect.w * rect.h, BLOCK)), dim3(BLOCK), 0, root.comm_stream,
+                           gathered, stride, static_cast<uint32_t>(n), rect.w, rect.h, rect.tiles_x, static_cast<uint8_t*>(rgb_dev));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(root.multi_exchange_end[set], root.comm_stream));
+        for (int d = 1; d < n; ++d) {      // the senders: their tile buffers may be written again once this has happened
+            DeviceBinding other(g_devices[d]);
+            HIP_TRY(hipEventRecord(g_devices[d].multi_sent[set], g_devices[d].comm_stream));
+        }
+        frame.busy = true; frame.n = n; frame.timed = want_stats != 0;
+        g_multi_next = 1 - set;
+        *ticket = set;
+        return 0;
+    });
+}
+
+int rt_render_multi_end(int ticket, rt_stats* stats_per_device, double* exchange_ms) {
+    if (ticket < 0 || ticket > 1) return rt_fail(RT_ERR_ARGUMENT, "rt_render_multi_end: no such ticket");
+    return guarded([&]() -> int {
+        std::lock_guard<std::mutex> one_at_a_time(g_multi_guard);
+        MultiFrame& frame = g_multi_frames[ticket];
+        if (!frame.busy) return rt_fail(RT_ERR_ARGUMENT, "rt_render_multi_end: no frame under way with this ticket");
+        frame.busy = false;
+        Library& root = g_devices[0];
+        HIP_TRY(hipEventSynchronize(root.multi_exchange_end[ticket]));
+        for (int d = 1; d < frame.n; ++d) HIP_TRY(hipEventSynchronize(g_devices[d].multi_sent[ticket]));
+        if (exchange_ms) {
+            float ms = 0.0f;
+            *exchange_ms = hipEventElapsedTime(&ms, root.multi_exchange_begin[ticket], root.multi_exchange_end[ticket]) == hipSuccess ? ms : 0.0;
+        }
+        if (stats_per_device) {
+            if (frame.timed) std::memcpy(stats_per_device, frame.stats, sizeof(rt_stats) * static_cast<size_t>(frame.n));
+            else std::memset(stats_per_device, 0, sizeof(rt_stats) * static_cast<size_t>(frame.n));
+        }
+        return 0;
+    });
 }
 
 int rt_render_multi(const rt_scene* scene, const rt_camera_desc* camera, const rt_render_params* params, uint8_t* rgb_out, rt_stats* stats_per_device) {
     const int n = g_multi_devices.load();
     if (n < 1) return rt_fail(RT_ERR_DEVICE, "rt_render_multi: rt_init_devices has not been called");
     if (!scene || !camera || !params || !rgb_out) return rt_fail(RT_ERR_ARGUMENT, "rt_render_multi: null argument");
-    return guarded([&]() -> int {
-        const Rect rect = rect_of(*params);
-        if (rect.w == 0 || rect.h == 0) return rt_fail(RT_ERR_ARGUMENT, "rt_render_multi: empty rectangle");
-        const uint32_t stride = ceil_div(rect.tiles, static_cast<uint32_t>(n));
-        const size_t bytes = static_cast<size_t>(stride) * 768, image_bytes = static_cast<size_t>(rect.w) * rect.h * 3;
-        // one host thread per device (the caller's takes device 0): its share of the tiles into its tile buffer
-        int rc_of[MAX_DEVICES] = {};
-        std::string error_of[MAX_DEVICES];
-        auto run_device = [&](int d) {
-            Library& lib = g_devices[d];
-            DeviceBinding bound(lib);
-            int rc = bound.ok ? 0 : rt_fail(RT_ERR_DEVICE, "rt_render_multi: hipSetDevice failed");
-            if (!rc) rc = grow(&lib.multi_tiles, &lib.multi_tiles_bytes, bytes);
-            if (!rc && d == 0) rc = grow(&lib.multi_gathered, &lib.multi_gathered_bytes, bytes * n);
-            if (!rc && d == 0) rc = grow(&lib.multi_image, &lib.multi_image_bytes, image_bytes);
-            if (!rc) {
-                rt_render_params mine = *params;
-                mine.tile_rank = static_cast<uint32_t>(d);
-                mine.tile_world = static_cast<uint32_t>(n);
-                rc = render_impl(scene, camera, &mine, lib.multi_tiles, nullptr, stats_per_device ? stats_per_device + d : nullptr);   // returns with the device's streams idle
-            }
-            rc_of[d] = rc;
-            if (rc) error_of[d] = g_last_error;
-        };
-        {
-            std::vector<std::thread> helpers;
-            for (int d = 1; d < n; ++d) helpers.emplace_back(run_device, d);
-            run_device(0);
-            for (std::thread& t : helpers) t.join();
-        }
-        for (int d = 0; d < n; ++d) if (rc_of[d]) return rt_fail(rc_of[d], error_of[d].c_str());
-        Library& root = g_devices[0];
+    const Rect rect = rect_of(*params);
+    const size_t image_bytes = static_cast<size_t>(rect.w) * rect.h * 3;
+    Library& root = g_devices[0];
+    {
         DeviceBinding bound(root);
-        const uint8_t* gathered = root.multi_tiles;
-        if (root.comm) {
-            Library* devices[MAX_DEVICES];
-            const uint8_t* send[MAX_DEVICES];
-            for (int d = 0; d < n; ++d) { devices[d] = &g_devices[d]; send[d] = g_devices[d].multi_tiles; }
-            if (int rc = enqueue_gather(devices, send, n, bytes, root.multi_gathered)) return rc;
-            gathered = root.multi_gathered;
-        }
-        rt_render_params whole = *params;
-        whole.tile_rank = 0; whole.tile_world = static_cast<uint32_t>(n);
-        hipLaunchKernelGGL(k_assemble, dim3(ceil_div(rect.w * rect.h, BLOCK)), dim3(BLOCK), 0, root.comm_stream,
-                           gathered, stride, static_cast<uint32_t>(n), rect.w, rect.h, rect.tiles_x, root.multi_image);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(rgb_out, root.multi_image, image_bytes, hipMemcpyDeviceToHost, root.comm_stream));
-        HIP_TRY(hipStreamSynchronize(root.comm_stream));
-        for (int d = 1; d < n; ++d) {      // the senders' streams, so that their tile buffers may be written again
-            DeviceBinding other(g_devices[d]);
-            HIP_TRY(hipStreamSynchronize(g_devices[d].comm_stream));
-        }
-        return 0;
-    });
+        std::lock_guard<std::mutex> one_at_a_time(root.guard);
+        if (int rc = grow(&root.multi_image, &root.multi_image_bytes, image_bytes ? image_bytes : 1)) return rc;
+    }
+    int ticket = -1;
+    if (int rc = rt_render_multi_begin(scene, camera, params, root.multi_image, stats_per_device ? 1 : 0, &ticket)) return rc;
+    if (int rc = rt_render_multi_end(ticket, stats_per_device, nullptr)) return rc;
+    DeviceBinding bound(root);
+    HIP_TRY(hipMemcpy(rgb_out, root.multi_image, image_bytes, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 }  // extern "C"

@@ -32,6 +32,7 @@ def _common_protos(prefix):
         prefix + "intersect_sphere8": (None, [_P(_f3), _P(_f3), C.c_void_p, _P(C.c_float * 8)]),
         prefix + "ellipsoid8": (None, [_P(_f3), _P(_f3), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
         prefix + "ellipsoid8_blocks": (C.c_int, [_P(_f3), _P(_f3), C.c_int, C.c_void_p, _P(_f3)]),
+        prefix + "worker_seconds": (C.c_int, [C.c_void_p, C.c_int]),
         prefix + "trace": (None, [_P(abi.SceneDesc), _P(_f3), _P(_f3), C.c_int, _P(_f3)]),
         prefix + "camera_setup": (None, [_P(C.c_float * 11), _P(abi.CameraDesc)]),
     }
@@ -69,13 +70,21 @@ def load_ref():
     return abi.bind(lib, protos)
 
 
+def available_cpus():
+    """Hardware threads this process may run on (its affinity mask; the machine's count where that is not known)."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
 def vec3(v):
     return _f3(*[float(x) for x in v])
 
 
 def cpu_render(lib, prefix, desc, cam, params, want_ids=False, want_colours=False, threads=None):
     """Render with the oracle ("rto_") or the reference ("ref_"). Returns dict(rgb, ids, colours, stats, seconds)."""
-    threads = threads or min(os.cpu_count() or 1, 16)
+    threads = threads or available_cpus()
     rw = params.rect_w or params.width
     rh = params.rect_h if params.rect_w else params.height
     rgb = np.zeros((rh, rw, 3), np.uint8)
@@ -90,7 +99,9 @@ def cpu_render(lib, prefix, desc, cam, params, want_ids=False, want_colours=Fals
     else:
         rc = lib.ref_render(C.byref(desc), C.byref(cam), C.byref(params), rgb.ctypes.data, pid, pc, threads, C.byref(secs))
     assert rc == 0
-    return {"rgb": rgb, "ids": ids, "colours": cols, "stats": stats, "seconds": secs.value}
+    busy = np.zeros(threads, np.float64)
+    getattr(lib, prefix + "worker_seconds")(busy.ctypes.data, threads)
+    return {"rgb": rgb, "ids": ids, "colours": cols, "stats": stats, "seconds": secs.value, "worker_seconds": busy, "threads": threads}
 
 
 def desc_arrays(desc):

@@ -83,6 +83,28 @@ multi = api.render_multi(scene, fi.camera(), prm, 1)
 single = scene.render(fi.camera(), prm)
 assert np.array_equal(multi["rgb"], single["rgb"]) and multi["rgb"].any()
 assert multi["stats"][0].closest_rays == single["stats"].closest_rays and multi["stats"][0].hits == single["stats"].hits
+# the same frame in two halves, the image left on the device; two frames under way, a third refused; then the single-device
+# entry points from this thread (its HIP device must be the first context's again)
+frames = [torch.zeros(multi["rgb"].size, dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+torch.cuda.synchronize()
+t0 = api.render_multi_begin(scene, fi.camera(), prm, frames[0].data_ptr())
+t1 = api.render_multi_begin(scene, fi.camera(), prm, frames[1].data_ptr(), want_stats=False)
+try:
+    api.render_multi_begin(scene, fi.camera(), prm, frames[2].data_ptr())
+    raise SystemExit("a third frame was accepted")
+except api.RtError as e:
+    assert "two frames are under way" in str(e)
+stats0, ms0 = api.render_multi_end(t0, 1)
+t2 = api.render_multi_begin(scene, fi.camera(), prm, frames[2].data_ptr())
+api.render_multi_end(t1, 1)
+stats2, ms2 = api.render_multi_end(t2, 1)
+for f in frames:
+    assert np.array_equal(f.cpu().numpy().reshape(multi["rgb"].shape), single["rgb"])
+assert stats0[0].hits == single["stats"].hits and stats2[0].shadow_blocked == single["stats"].shadow_blocked and ms0 > 0.0
+again = scene.render(fi.camera(), prm)
+assert np.array_equal(again["rgb"], single["rgb"])
+out = api.debug_eval(0, np.array([0.5], np.float32), np.array([1.0], np.float32))
+assert out.view(np.uint32)[0] == 0x3EFFF992
 print("MULTI_OK")
 """
 
