@@ -97,11 +97,13 @@ typedef struct rt_render_params {
 #define RT_TILE 16u
 #define RT_SAMPLES_PER_PIXEL 16u  /* SQRT_SAMPLES_PER_PIXEL^2, render_work_queue.cpp:24-29 */
 
-#define RT_FLAG_NO_FILTER 1u      /* run every ray-primitive test through the full test; no bounding hierarchy, no conservative pre-test */
+#define RT_FLAG_NO_FILTER 1u      /* brute force: every ray is tested against every primitive, no bounding hierarchy */
 #define RT_FLAG_WALK_ALL  2u      /* walk the bounding hierarchy of every primitive kind, also of kinds so small that the
                                      library would scan them by brute force (same results; for tests and tuning) */
-#define RT_FLAG_PLAIN_TEST 8u     /* brute-force triangle scans evaluate the test exactly as written (three IEEE divisions per pair) instead of
-                                     in stages that skip what the outcome does not depend on (same results; for measurements) */
+#define RT_FLAG_PLAIN_TEST 8u     /* brute-force scans evaluate every test exactly as written (triangles: three IEEE divisions per pair) instead of
+                                     deciding most pairs by a conservative pre-test first (same results; for measurements) */
+#define RT_FLAG_EXACT_STAGES 16u  /* brute-force triangle scans evaluate the test in exact stages (the division without its range handling, comparisons of
+                                     the numerators) instead of conservative pre-tests followed by the test as written (same results; for measurements) */
 #define RT_FLAG_DEEP_WALK 4u      /* walk every hierarchy the way the library walks big ones (closest-hit rays from the super
                                      nodes, shadow rays depth first) whatever its size (same results; for tests and tuning) */
 
@@ -148,6 +150,9 @@ typedef struct rt_stats {
     uint64_t walk_steps[2];         /* steps of up to 64 (ray, node) pairs, one pair per lane, below that level: 64 * walk_steps against the
                                        pairs walked ((pair_pretests - per-ray tests of the first level) / 16) is the fill of the lanes; for the
                                        depth-first walk a step serves either the lanes that hold a node or those that hold a leaf */
+    uint64_t brute_wave_steps[2][4]; /* brute-force triangle scans in their default form, closest-hit / shadow: (wavefront, triangle) steps in all (64 lanes
+                                       x 2 rays per lane in the closest-hit scan, x 1 in the shadow scan), of which went past the sign test of the two dot
+                                       products (rays of one origin skip that test), of which reached the second pre-test, of which reached the test as written */
 } rt_stats;
 
 /* Thread safety: a GPU has one set of streams and ray-state arenas per frame slot; rt_scene_create, the render calls,

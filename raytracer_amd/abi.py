@@ -85,13 +85,14 @@ class Stats(C.Structure):
         ("walk_waves", C.c_uint64 * 2),
         ("first_level_nodes", C.c_uint64 * 2),
         ("walk_steps", C.c_uint64 * 2),
+        ("brute_wave_steps", (C.c_uint64 * 4) * 2),
     ]
 
     def as_dict(self):
         out = {}
         for name, _ in self._fields_:
             v = getattr(self, name)
-            out[name] = list(v) if hasattr(v, "__len__") else v
+            out[name] = [list(x) if hasattr(x, "__len__") else x for x in v] if hasattr(v, "__len__") else v
         return out
 
 
@@ -102,6 +103,7 @@ RT_FLAG_NO_FILTER = 1
 RT_FLAG_WALK_ALL = 2
 RT_FLAG_DEEP_WALK = 4
 RT_FLAG_PLAIN_TEST = 8
+RT_FLAG_EXACT_STAGES = 16
 (RT_DEBUG_FP_POW, RT_DEBUG_FP_MIN, RT_DEBUG_FP_MAX, RT_DEBUG_DIVIDE, RT_DEBUG_DIVIDE_IN_RANGE, RT_DEBUG_PRIMARY_RAY,
  RT_DEBUG_SCENE_BOX, RT_DEBUG_TRIANGLE, RT_DEBUG_TRIANGLE_STAGED, RT_DEBUG_SPHERE, RT_DEBUG_ELLIPSOID, RT_DEBUG_ELLIPSOID_STAGED,
  RT_DEBUG_ELLIPSOID_SHADOW, RT_DEBUG_ELLIPSOID_SHADOW_STAGED, RT_DEBUG_ELLIPSOID_PARTS) = range(15)

@@ -165,7 +165,8 @@ struct State {
 constexpr int STAT_COPIES = 64;
 enum { ST_SAMPLES, ST_CULLED, ST_CLOSEST_RAYS, ST_HITS, ST_SHADOW_RAYS, ST_SHADOW_BLOCKED,
        ST_SHADOW_TESTS_TRI, ST_SHADOW_TESTS_SPH, ST_SHADOW_TESTS_ELL, ST_FULL_TESTS, ST_PAIR_PRETESTS, ST_PAIR_PRETESTS_SHADOW, ST_LIVE, ST_QUEUED, ST_QUEUED_SHADOW, ST_FLOP, ST_FLOP_SHADOW,
-       ST_FIRST_NODES, ST_FIRST_NODES_SHADOW, ST_WALK_BATCHES, ST_WALK_BATCHES_SHADOW, ST_WALK_WAVES, ST_WALK_WAVES_SHADOW, ST_COUNT };
+       ST_FIRST_NODES, ST_FIRST_NODES_SHADOW, ST_WALK_BATCHES, ST_WALK_BATCHES_SHADOW, ST_WALK_WAVES, ST_WALK_WAVES_SHADOW,
+       ST_BRUTE_STEPS, ST_BRUTE_STAGE1, ST_BRUTE_STAGE2, ST_BRUTE_EXACT, ST_BRUTE_STEPS_SHADOW, ST_BRUTE_STAGE1_SHADOW, ST_BRUTE_STAGE2_SHADOW, ST_BRUTE_EXACT_SHADOW, ST_COUNT };
 
 struct V3 { float x, y, z; };
 
@@ -421,6 +422,36 @@ DEV bool pretest_stage1(V3 o, V3 d, float o_max, float4 f0, float4 f1, float4 f2
     const float t1 = num * __builtin_amdgcn_rcpf(dn);
     s.ap = V3{fma_(t1, d.x, -ao.x), fma_(t1, d.y, -ao.y), fma_(t1, d.z, -ao.z)};
     s.alpha = vdot(s.ap, w1);
+    s.thr = fma_(f0.w, __builtin_fabsf(t1) + o_max, f1.w);
+    return !(__builtin_fabsf(s.alpha - 0.5f) > s.thr);
+}
+// The same for rays that all start at one point: a - o and (a - o).n are then properties of the triangle, computed once per
+// tile (stage_pretest_tile) with the very expressions above.  p0 = (n, (a-o).n), p1 = (a - o, Ga), p2 = (w1, Ha).
+DEV bool pretest_stage1_shared(V3 d, float o_max, float4 p0, float4 p1, float4 p2, Pre& s) {
+    const float dn = vdot(d, xyz(p0));
+    const float t1 = p0.w * __builtin_amdgcn_rcpf(dn);
+    s.ap = V3{fma_(t1, d.x, -p1.x), fma_(t1, d.y, -p1.y), fma_(t1, d.z, -p1.z)};
+    s.alpha = vdot(s.ap, xyz(p2));
+    s.thr = fma_(p1.w, __builtin_fabsf(t1) + o_max, p2.w);
+    return !(__builtin_fabsf(s.alpha - 0.5f) > s.thr);
+}
+// pretest_stage1 in two parts for the brute-force scans of rays with origins of their own, whose triangles lie behind them as
+// often as ahead: the two dot products first - if they differ in sign the quotient t of the full test is <= -0, below the
+// tolerance, and the pair is a certain miss (a NaN has no meaningful sign, but then the full test returns NaN or FLT_MAX, never a
+// hit); a wave all of whose rays have the triangle behind them goes to the next one after 11 issue slots instead of 24.
+struct PreFront { float dn, num; V3 ao; };
+DEV PreFront pretest_front(V3 o, V3 d, float4 f0, float4 f1, bool& behind) {
+    PreFront p;
+    p.dn = vdot(d, xyz(f0));
+    p.ao = sub(xyz(f1), o);
+    p.num = vdot(p.ao, xyz(f0));
+    behind = static_cast<int>(__float_as_uint(p.dn) ^ __float_as_uint(p.num)) < 0;
+    return p;
+}
+DEV bool pretest_stage1_rest(const PreFront& p, V3 d, float o_max, float4 f0, float4 f1, float4 f2, Pre& s) {
+    const float t1 = p.num * __builtin_amdgcn_rcpf(p.dn);
+    s.ap = V3{fma_(t1, d.x, -p.ao.x), fma_(t1, d.y, -p.ao.y), fma_(t1, d.z, -p.ao.z)};
+    s.alpha = vdot(s.ap, xyz(f2));
     s.thr = fma_(f0.w, __builtin_fabsf(t1) + o_max, f1.w);
     return !(__builtin_fabsf(s.alpha - 0.5f) > s.thr);
 }
@@ -1638,6 +1669,89 @@ DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, con
         }
     }
 }
+// The default form of the brute-force triangle scans: every (ray, triangle) pair is visited and decided either by the two-stage
+// conservative pre-test (pretest_stage1 / pretest_stage2: the reference's own d.n and (a-o).n, a reciprocal instead of the
+// division, and the barycentrics from precomputed w1, w2 with proven margins - the test the hierarchy's leaves use) or, for
+// the pairs it keeps, by the test as written (hit_triangle).  A wave goes on to the next stage only when one of its lanes
+// kept the pair, which in a scene of small triangles happens once in a few hundred steps: the common path is stage 1, 18 issue
+// slots for rays with one origin and 24 for any rays, against 40 / 48 of the exact stages (tri_front / tri_head) and 96.5 of the
+// test as written.  The tile in LDS holds the pre-test records (stage_pretest_tile); the full-test record of a pair that
+// reaches the test as written is read from memory (one 64-byte line for the whole wave).
+// Counters (per wave, uniform): steps that reached the second stage and the test as written.
+DEV void stage_pretest_tile(float4* lds, const float4* __restrict__ trif, uint32_t first, uint32_t count, bool shared, V3 o) {
+    if (threadIdx.x >= count) return;
+    const float4* g = trif + static_cast<size_t>(first + threadIdx.x) * 4;
+    const float4 f0 = g[0], f1 = g[1], f2 = g[2], f3 = g[3];      // (n, Ga) (a, Ha) (w1, -) (w2, -)
+    if (shared) {
+        const V3 ao = sub(xyz(f1), o);
+        lds[threadIdx.x] = make_float4(f0.x, f0.y, f0.z, vdot(ao, xyz(f0)));
+        lds[TILE_PRIMS + threadIdx.x] = make_float4(ao.x, ao.y, ao.z, f0.w);
+        lds[2 * TILE_PRIMS + threadIdx.x] = make_float4(f2.x, f2.y, f2.z, f1.w);
+    } else {
+        lds[threadIdx.x] = f0;
+        lds[TILE_PRIMS + threadIdx.x] = f1;
+        lds[2 * TILE_PRIMS + threadIdx.x] = f2;
+    }
+    lds[3 * TILE_PRIMS + threadIdx.x] = f3;
+}
+struct BruteCounts { uint32_t steps = 0, stage1 = 0, stage2 = 0, exact = 0; };
+template <int R, bool SHARED, typename Visit>
+DEV void pretest_tile(const float4* lds, const float4* __restrict__ records, uint32_t first, uint32_t count, const V3 (&o)[R], const V3 (&d)[R],
+                      const float (&o_max)[R], Mask everyone, BruteCounts& counts, Visit&& visit) {
+    counts.steps += count;
+    // Every part of a record is read as one 16-byte read: left alone the compiler reads the words a stage needs with 12-byte and
+    // strided reads, which occupy the LDS twice as long (the four SIMDs of a CU share it), so all four words are declared used.
+#define RT_WHOLE_WORD(v) asm volatile("" : : "v"((v).x), "v"((v).y), "v"((v).z), "v"((v).w))
+    for (uint32_t k = 0; k < count; ++k) {
+        const float4 p0 = lds[k], p1 = lds[TILE_PRIMS + k];
+        RT_WHOLE_WORD(p0); RT_WHOLE_WORD(p1);
+        float4 p2;
+        if (SHARED) { p2 = lds[2 * TILE_PRIMS + k]; RT_WHOLE_WORD(p2); }
+        Pre pre[R];
+        bool kept[R];
+        Mask keep = 0;
+        if (SHARED) {      // (triangles behind the eye are rare: no sign test)
+            counts.stage1++;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { kept[r] = pretest_stage1_shared(d[r], o_max[r], p0, p1, p2, pre[r]); keep |= ballot(kept[r]); }
+        } else {
+            PreFront front[R];
+            bool behind[R];
+            Mask ahead = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { front[r] = pretest_front(o[r], d[r], p0, p1, behind[r]); ahead |= ballot(!behind[r]); }
+            if ((ahead & everyone) == 0) continue;
+            counts.stage1++;
+            p2 = lds[2 * TILE_PRIMS + k];
+            RT_WHOLE_WORD(p2);
+#pragma unroll
+            for (int r = 0; r < R; ++r) { kept[r] = pretest_stage1_rest(front[r], d[r], o_max[r], p0, p1, p2, pre[r]) && !behind[r]; keep |= ballot(kept[r]); }
+        }
+        if ((keep & everyone) == 0) continue;
+        counts.stage2++;
+        const float4 p3 = lds[3 * TILE_PRIMS + k];
+        RT_WHOLE_WORD(p3);
+        keep = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { kept[r] = kept[r] && pretest_stage2(pre[r], p3); keep |= ballot(kept[r]); }
+        if ((keep & everyone) == 0) continue;
+        counts.exact++;
+        const float4* rec = records + static_cast<size_t>(first + k) * 4;
+        const float4 t0 = rec[0], t1 = rec[1], t2 = rec[2];
+        const float nn = rec[3].x;
+#pragma unroll
+        for (int r = 0; r < R; ++r) visit(r, first + k, hit_triangle(o[r], d[r], t0, t1, t2, nn));
+    }
+#undef RT_WHOLE_WORD
+}
+DEV void add_brute_counts(const State& st, const BruteCounts& c, int first_stat) {
+    if ((threadIdx.x & 63u) != 0) return;
+    if (c.steps) atomicAdd(stat_slot(st, first_stat), static_cast<unsigned long long>(c.steps));
+    if (c.stage1) atomicAdd(stat_slot(st, first_stat + 1), static_cast<unsigned long long>(c.stage1));
+    if (c.stage2) atomicAdd(stat_slot(st, first_stat + 2), static_cast<unsigned long long>(c.stage2));
+    if (c.exact) atomicAdd(stat_slot(st, first_stat + 3), static_cast<unsigned long long>(c.exact));
+}
+
 // Reflected rays for the brute-force closest-hit scan, ordered by direction.  The staged test skips a stage when no ray of
 // the wave needs it, and the rays a wave takes from the list in image order were reflected by different small triangles:
 // they point anywhere.  A copy of the list in the order of 512 direction bins (3 bits per component; within a bin in the
@@ -1709,8 +1823,11 @@ __global__ void __launch_bounds__(BLOCK) k_bin_scatter(DevScene sc, State st, ui
 }
 
 // `list`: the rays in the order the scan takes them (the list of the bounce, or its copy in the order of k_bin_scatter)
-template <int R, bool STAGED>
+// FORM: 0 the test as written on every pair (RT_FLAG_PLAIN_TEST); 1 the test in exact stages (RT_FLAG_EXACT_STAGES);
+// 2 conservative pre-tests, then the test as written for the pairs they keep (pretest_tile; the default).
+template <int R, int FORM>
 __global__ void __launch_bounds__(BLOCK) k_closest_tri_brute(DevScene sc, State st, uint32_t bounce, const uint32_t* __restrict__ list) {
+    constexpr bool STAGED = FORM == 1;
     __shared__ float4 lds[TILE_PRIMS * 4];
     const uint32_t n_rays = st.counts[bounce];
     const uint32_t base = blockIdx.x * (BLOCK * R);
@@ -1735,11 +1852,29 @@ __global__ void __launch_bounds__(BLOCK) k_closest_tri_brute(DevScene sc, State 
     __syncthreads();
     const V3 o_block{lds_origin[0], lds_origin[1], lds_origin[2]};
     same = same && o[0].x == o_block.x && o[0].y == o_block.y && o[0].z == o_block.z;
-    const bool shared_origin = STAGED && __syncthreads_and(same && tame);
+    const bool shared_origin = FORM != 0 && __syncthreads_and(same && (tame || FORM == 2));
     auto visit = [&](int r, uint32_t k, float t) __attribute__((always_inline)) {
         if (t < best_t[r]) { best_t[r] = t; best_k[r] = k; }
     };
     const Mask everyone = ballot(true);
+    if (FORM == 2) {
+        float o_max[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) o_max[r] = fmaxf(fabsf(o[r].x), fmaxf(fabsf(o[r].y), fabsf(o[r].z)));
+        BruteCounts counts;
+        for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
+            const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
+            __syncthreads();
+            stage_pretest_tile(lds, sc.trif, first, count, shared_origin, o_block);
+            __syncthreads();
+            if (shared_origin) pretest_tile<R, true>(lds, sc.tri, first, count, o, d, o_max, everyone, counts, visit);
+            else pretest_tile<R, false>(lds, sc.tri, first, count, o, d, o_max, everyone, counts, visit);
+        }
+        add_brute_counts(st, counts, ST_BRUTE_STEPS);
+#pragma unroll
+        for (int r = 0; r < R; ++r) if (valid[r]) st.key[slot[r]] = best_k[r] == 0xFFFFFFFFu ? NO_HIT_KEY : pack_hit(best_t[r], best_k[r]);
+        return;
+    }
     for (uint32_t first = 0; first < sc.n_tri; first += TILE_PRIMS) {
         const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
         __syncthreads();
@@ -2620,11 +2755,12 @@ DEV ShadowRay make_shadow_ray(const State& st, uint32_t slot, bool point, V3 lv)
 #define RT_SHADOW_BRUTE_ATTR __attribute__((amdgpu_waves_per_eu(8)))
 #endif
 constexpr uint32_t SHADOW_COMPACT_TILES = RT_SHADOW_COMPACT_TILES, SHADOW_RANGE_BLOCKS = RT_SHADOW_RANGE_BLOCKS, SHADOW_MIN_RANGES = RT_SHADOW_MIN_RANGES;
-template <bool STAGED>
+template <int FORM>
 __global__ void __launch_bounds__(BLOCK) RT_SHADOW_BRUTE_ATTR k_shadow_tri_brute(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first, const uint32_t* __restrict__ list_in) {
     __shared__ float4 lds[TILE_PRIMS * 4];
     // Rays change lanes through the tile's memory, between two tiles: (o, limit) (d, tiles left) and the slot of the
     // rays the workgroup holds, by lane.  (Memory of their own would leave six workgroups per CU instead of nine.)
+    constexpr bool STAGED = FORM == 1;
     float4 (*parked)[BLOCK] = reinterpret_cast<float4 (*)[BLOCK]>(lds);
     uint32_t* parked_slot = reinterpret_cast<uint32_t*>(lds + 2 * BLOCK);
     static_assert(TILE_PRIMS * 4 >= 2 * BLOCK + BLOCK / 4, "the parked rays fit the tile");
@@ -2714,6 +2850,126 @@ __global__ void __launch_bounds__(BLOCK) RT_SHADOW_BRUTE_ATTR k_shadow_tri_brute
         }
     }
     if (lane == 0 && wave_tests) atomicAdd(stat_slot(st, ST_SHADOW_TESTS_TRI), wave_tests);
+}
+
+// The same scan in the default form of the brute-force triangle scans (pretest_tile), R rays per lane: the pre-test reads
+// three 16-byte words of LDS per step for 24 issue slots of arithmetic, so with one ray per lane the LDS - shared by the four
+// SIMDs of a CU - limits the scan as much as the arithmetic does; two rays per lane share each read.  The workgroup holds
+// BLOCK x R rays, ray i in lane i % BLOCK as its ray number i / BLOCK; every SHADOW_COMPACT_TILES tiles the open ones move to
+// the front (in order) and the room behind them is filled from the workgroup's range of the list.  Only a ray's slot and the
+// number of tiles it has still to see change lanes (8 bytes per ray, through the tile's memory between two tiles); the ray
+// itself is rebuilt from its hit point (make_shadow_ray: the same expressions give the same bits).
+template <int R>
+__global__ void __launch_bounds__(BLOCK) RT_SHADOW_BRUTE_ATTR k_shadow_tri_pretest(DevScene sc, State st, uint32_t bounce, uint32_t first_light, uint32_t group_first, const uint32_t* __restrict__ list_in) {
+    __shared__ float4 lds[TILE_PRIMS * 4];
+    constexpr uint32_t CAPACITY = BLOCK * R, WAVES = BLOCK / 64;
+    uint2* parked = reinterpret_cast<uint2*>(lds);        // (slot, tiles left) of the rays the workgroup holds, between two tiles
+    static_assert(sizeof(uint2) * CAPACITY <= sizeof(float4) * TILE_PRIMS * 4, "the parked rays fit the tile");
+    __shared__ uint32_t wave_open[R * WAVES];
+    const uint32_t n_rays = st.counts[bounce + 1];
+    const uint32_t n_blocks = (n_rays + BLOCK - 1) / BLOCK;
+    const uint32_t blocks_per_wg = min(SHADOW_RANGE_BLOCKS * R, max(1u, n_blocks * gridDim.y / SHADOW_MIN_RANGES));
+    if (static_cast<unsigned long long>(blockIdx.x) * blocks_per_wg >= n_blocks) return;      // (also: no rays)
+    uint32_t range_next = blockIdx.x * blocks_per_wg * BLOCK;                                 // the next ray of the range
+    const uint32_t range_end = static_cast<uint32_t>(min(static_cast<unsigned long long>(n_rays), static_cast<unsigned long long>(range_next) + static_cast<unsigned long long>(blocks_per_wg) * BLOCK));
+    const float* __restrict__ L = sc.lights + (first_light + blockIdx.y) * 8;
+    const bool point = L[0] != 0.0f;
+    const V3 lv{L[1], L[2], L[3]};
+    const uint32_t light_bit = 1u << (first_light + blockIdx.y - group_first);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n_tiles = (sc.n_tri + TILE_PRIMS - 1) / TILE_PRIMS;
+    const uint32_t interval = min(SHADOW_COMPACT_TILES, n_tiles);
+    uint32_t slot[R], left[R];
+    bool active[R], blocked[R];
+    V3 o[R], d[R];
+    float limit[R], o_max[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { slot[r] = 0; left[r] = 0; active[r] = false; blocked[r] = false; o[r] = d[r] = V3{0.0f, 0.0f, 0.0f}; limit[r] = 0.0f; o_max[r] = 0.0f; }
+    uint32_t held = 0;                         // rays 0 .. held - 1 are held
+    uint32_t tile = 0;                         // the tile of the list that is staged next
+    unsigned long long wave_tests = 0;
+    BruteCounts counts;
+    for (;;) {
+        // retire what is done, pack the open rays in order, take new ones
+        bool open[R];
+        Mask open_mask[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (active[r] && blocked[r]) atomicOr(&st.blocked[slot[r]], light_bit);
+            open[r] = active[r] && !blocked[r] && left[r] != 0u;
+            open_mask[r] = ballot(open[r]);
+            if (lane == 0) wave_open[r * WAVES + wave] = static_cast<uint32_t>(__popcll(open_mask[r]));
+        }
+        __syncthreads();
+        uint32_t before[R], total = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (uint32_t w = 0; w < WAVES; ++w) {
+                if (w == wave) before[r] = total;
+                total += wave_open[r * WAVES + w];
+            }
+        }
+        const uint32_t room = CAPACITY - total;
+        const uint32_t next = range_next;
+        const uint32_t take = min(room, range_end - range_next);
+        range_next += take;
+        if (total + take == 0) break;                                  // uniform over the workgroup: every ray of the range is done
+        if (total != held || take != 0) {                              // uniform
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (open[r]) parked[before[r] + static_cast<uint32_t>(__popcll(open_mask[r] & ((1ull << lane) - 1ull)))] = make_uint2(slot[r], left[r]);
+            for (uint32_t j = threadIdx.x; j < take; j += BLOCK) {
+                const uint32_t s = list_in[next + j];
+                const bool blocked_before = (st.blocked[s] & light_bit) != 0u;         // (by a scan of another kind of primitive)
+                parked[total + j] = make_uint2(s, blocked_before ? 0u : n_tiles);
+            }
+            __syncthreads();
+            held = total + take;
+            // a lane without a ray of some number repeats a ray the workgroup holds (its results are dropped), so that it meets no
+            // operands of its own
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t i = static_cast<uint32_t>(r) * BLOCK + threadIdx.x, wave_first = static_cast<uint32_t>(r) * BLOCK + wave * 64u;
+                active[r] = i < held;
+                const uint2 mine = parked[active[r] ? i : (wave_first < held ? wave_first : 0u)];
+                slot[r] = mine.x; left[r] = mine.y;
+                const ShadowRay ray = make_shadow_ray(st, slot[r], point, lv);
+                o[r] = ray.o; d[r] = ray.d; limit[r] = ray.limit;
+                o_max[r] = fmaxf(fabsf(ray.o.x), fmaxf(fabsf(ray.o.y), fabsf(ray.o.z)));
+                blocked[r] = false;
+            }
+        }
+        for (uint32_t step = 0; step < interval; ++step) {
+            const uint32_t first = tile * TILE_PRIMS;
+            const uint32_t count = min(static_cast<uint32_t>(TILE_PRIMS), sc.n_tri - first);
+            __syncthreads();
+            stage_pretest_tile(lds, sc.trif, first, count, false, V3{0.0f, 0.0f, 0.0f});
+            __syncthreads();
+            Mask testing = 0;
+            bool counted[R];
+            uint32_t n_testing = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                counted[r] = active[r] && !blocked[r] && left[r] != 0u;
+                const Mask m = ballot(counted[r]);
+                testing |= m;
+                n_testing += static_cast<uint32_t>(__popcll(m));
+            }
+            if (testing != 0) {
+                wave_tests += static_cast<unsigned long long>(count) * n_testing;
+                // (a lane of `testing` may hold a ray that does not count beside one that does: its result is computed like any other and dropped)
+                pretest_tile<R, false>(lds, sc.tri, first, count, o, d, o_max, testing, counts, [&](int r, uint32_t, float t) __attribute__((always_inline)) {
+                    blocked[r] |= (t < limit[r]) & counted[r];
+                });
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) left[r] -= left[r] != 0u ? 1u : 0u;
+            tile = tile + 1 == n_tiles ? 0u : tile + 1;
+        }
+    }
+    if (lane == 0 && wave_tests) atomicAdd(stat_slot(st, ST_SHADOW_TESTS_TRI), wave_tests);
+    add_brute_counts(st, counts, ST_BRUTE_STEPS_SHADOW);
 }
 
 // Any-hit of every hit point toward light first_light + blockIdx.y over the primitives of kind PRIM:
@@ -3656,6 +3912,16 @@ constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE;   // brute-force scans over sphe
 #define RT_TRI_RAYS_PER_LANE 1
 #endif
 constexpr int TRI_RAYS_PER_LANE = RT_TRI_RAYS_PER_LANE;
+// The pre-test form reads three 16-byte words of LDS per step for 18 issue slots of arithmetic (rays with one origin): with one
+// ray per lane the LDS, shared by the four SIMDs of a CU, is the limit; two rays per lane share each read.
+#ifndef RT_PRETEST_RAYS_PER_LANE
+#define RT_PRETEST_RAYS_PER_LANE 2
+#endif
+constexpr int PRETEST_RAYS_PER_LANE = RT_PRETEST_RAYS_PER_LANE;
+#ifndef RT_PRETEST_SHADOW_RAYS_PER_LANE
+#define RT_PRETEST_SHADOW_RAYS_PER_LANE 1
+#endif
+constexpr int PRETEST_SHADOW_RAYS_PER_LANE = RT_PRETEST_SHADOW_RAYS_PER_LANE;
 #ifndef RT_SORT_RAYS_MIN_TRIANGLES
 #define RT_SORT_RAYS_MIN_TRIANGLES 2048
 #endif
@@ -3952,6 +4218,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
     const uint32_t depth = static_cast<uint32_t>(prm->max_bounce_count);
     const bool filter = (prm->flags & RT_FLAG_NO_FILTER) == 0;
     const bool plain_test = (prm->flags & RT_FLAG_PLAIN_TEST) != 0;
+    const bool exact_stages = (prm->flags & RT_FLAG_EXACT_STAGES) != 0;
     // per kind (0 triangles, 1 ellipsoids, 2 spheres): walk its hierarchy, or scan it by brute force
     const uint32_t below = (prm->flags & RT_FLAG_WALK_ALL) ? 0u : brute_force_below();
     const bool force_deep = (prm->flags & RT_FLAG_DEEP_WALK) != 0;
@@ -4044,7 +4311,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
             timed(timer, 0, on, [&] {
                 if (sc.n_tri) timed(timer, 2, on, [&] {
                     if (walk[0]) hierarchy_scan(0);
-                    else if (plain_test) hipLaunchKernelGGL((k_closest_tri_brute<TRI_RAYS_PER_LANE, false>), dim3(tri_scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b, static_cast<const uint32_t*>(sb.list[b & 1u]));
+                    else if (plain_test) hipLaunchKernelGGL((k_closest_tri_brute<TRI_RAYS_PER_LANE, 0>), dim3(tri_scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b, static_cast<const uint32_t*>(sb.list[b & 1u]));
                     else {
                         // reflected rays of a long scan are taken in the order of their directions (launches follow each other on one stream in this mode;
                         // the other list buffer is free until this bounce's compaction, the scan words between two compactions)
@@ -4057,7 +4324,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                             hipLaunchKernelGGL(k_bin_scatter<0>, dim3(ray_blocks()), dim3(BLOCK), 0, on, sc, sb, b, cursors, sb.list[(b + 1) & 1u]);
                             list = sb.list[(b + 1) & 1u];
                         }
-                        hipLaunchKernelGGL((k_closest_tri_brute<TRI_RAYS_PER_LANE, true>), dim3(tri_scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b, list);
+                        if (exact_stages) hipLaunchKernelGGL((k_closest_tri_brute<TRI_RAYS_PER_LANE, 1>), dim3(tri_scan_blocks()), dim3(BLOCK), 0, on, sc, sb, b, list);
+                        else hipLaunchKernelGGL((k_closest_tri_brute<PRETEST_RAYS_PER_LANE, 2>), dim3(ceil_div(std::max(bound, 1u), BLOCK * PRETEST_RAYS_PER_LANE)), dim3(BLOCK), 0, on, sc, sb, b, list);
                     }
                 });
                 if (sc.n_sph) timed(timer, 3, on, [&] {
@@ -4116,7 +4384,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                     // brute-force shadow scan of one kind toward lights first.. (n of them)
                     auto brute_force = [&](int prim, uint32_t n, uint32_t first_light) {
                         const dim3 grid(prim == 0 ? ray_blocks() : scan_blocks(), n);    // the triangle scan takes one ray per lane (and cuts the list into ranges of its own: a workgroup beyond the last range returns)
-                        if (prim == 0 && plain_test) hipLaunchKernelGGL((k_shadow_tri_brute<false>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0, static_cast<const uint32_t*>(sb.list[(b + 1) & 1u]));
+                        if (prim == 0 && plain_test) hipLaunchKernelGGL((k_shadow_tri_brute<0>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0, static_cast<const uint32_t*>(sb.list[(b + 1) & 1u]));
                         else if (prim == 0) {
                             // a long scan takes the hit points in the order of their cells (the list buffer of this bounce's rays is free after its compaction)
                             const uint32_t* list = sb.list[(b + 1) & 1u];
@@ -4131,7 +4399,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                                 }
                                 list = sb.list[b & 1u];
                             }
-                            hipLaunchKernelGGL((k_shadow_tri_brute<true>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0, list);
+                            if (exact_stages) hipLaunchKernelGGL((k_shadow_tri_brute<1>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0, list);
+                            else hipLaunchKernelGGL(k_shadow_tri_pretest<PRETEST_SHADOW_RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0, list);
                         }
                         else if (prim == 1 && plain_test) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                         else if (prim == 2 && plain_test) hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
@@ -4232,6 +4501,7 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
         stats->walk_steps[0] = h[ST_WALK_BATCHES]; stats->walk_steps[1] = h[ST_WALK_BATCHES_SHADOW];
         stats->walk_waves[0] = h[ST_WALK_WAVES]; stats->walk_waves[1] = h[ST_WALK_WAVES_SHADOW];
         stats->executed_flop[0] = h[ST_FLOP]; stats->executed_flop[1] = h[ST_FLOP_SHADOW];
+        for (int k = 0; k < 4; ++k) { stats->brute_wave_steps[0][k] = h[ST_BRUTE_STEPS + k]; stats->brute_wave_steps[1][k] = h[ST_BRUTE_STEPS_SHADOW + k]; }
         float ms = 0.0f;
         if (ev_begin && ev_end && hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) stats->device_ms = ms;
         double family_ms[8] = {};
