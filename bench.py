@@ -286,10 +286,14 @@ def main():
             out["frame_identical_to_single_rank_render"] = bool((alone["rgb"].reshape(-1) == frame.cpu().numpy()).all())
         if not args.brute_force:
             out["output_ms"] = output_stage(api, scene, cam, prm, tiles[0], frame, fi, torch, world)
-        if not args.no_brute_force_leg:
+        if args.brute_force and world == 1:
+            # the timed frames themselves were brute force: the table of the scans from their own launches (whole frames, not a crop)
+            out["roofline"], out["brute_force"] = whole_frame_roofline(stats, fi, args, label, depth, elapsed)
+            fast = scene.render(cam, fi.params(max_bounce_count=depth))
+            out["frame_identical_to_default_mode"] = bool((fast["rgb"].reshape(-1) == frame.cpu().numpy()).all())
+            out["counters_identical_to_default_mode"] = all(getattr(stats[-1], f) == getattr(fast["stats"], f) for f in ("closest_rays", "hits", "shadow_rays", "shadow_blocked"))
+        elif not args.no_brute_force_leg:
             out["roofline"], out["brute_force"] = brute_force_leg(abi, fi, cam, scene, depth, args, label)
-            if args.brute_force:   # the timed frames themselves were brute force: the whole-frame figures beside the leg's
-                out["brute_force"]["timed_frames"] = {"mrays_s": out["value"], "ms_per_step": out["ms_per_step"], "tests_per_s": pairs / elapsed}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(api, abi, fi, cam, scene, depth, args.cpu_crop or CPU_CROP.get(args.workload, CPU_CROP["default"]))
         sys.stdout.flush()
@@ -433,6 +437,34 @@ def kernel_table(st, fi, plain):
     total = {"what": "sum over kinds and scans of pairs x FLOP of the kind / sum of the scans' kernel seconds", "pairs": total_pairs, "flop": total_flop, "kernel_ms": total_ms,
              "pairs_per_s": total_pairs / (total_ms * 1e-3) if total_ms > 0 else 0.0, "achieved": tflops, "frac": tflops / PEAK_FP32_TFLOPS}
     return rows, total
+
+
+class SummedStats:
+    """The work counters and launch times of several rt_stats, added up (what kernel_table reads)."""
+    def __init__(self, stats):
+        for name in ("closest_tests", "shadow_tests", "closest_kind_ms", "shadow_kind_ms", "closest_kind_launches", "shadow_kind_launches"):
+            setattr(self, name, [sum(getattr(s, name)[k] for s in stats) for k in range(3)])
+        self.brute_wave_steps = [[sum(s.brute_wave_steps[i][k] for s in stats) for k in range(4)] for i in range(2)]
+        for name in ("closest_rays", "shadow_rays", "device_ms"):
+            setattr(self, name, sum(getattr(s, name) for s in stats))
+
+
+def whole_frame_roofline(stats, fi, args, label, depth, elapsed):
+    """--brute-force: the `roofline` and `brute_force` objects from the launches of the timed frames themselves."""
+    st = SummedStats(stats)
+    rows, total = kernel_table(st, fi, args.plain_test)
+    closest_rows = {k: v for k, v in rows.items() if k.startswith("closest_")}
+    head_name = max(closest_rows, key=lambda k: closest_rows[k]["ms"]) if closest_rows else None
+    out = {"bound": "valu_fp32", "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s"}
+    out.update(dict(rows[head_name]) if head_name else {"kernel": None, "achieved": 0.0, "frac": 0.0})
+    out.update({"traffic": None, "sample": "the %d timed frames of %s, whole, maxdepth %d: %d closest-hit rays, %d shadow rays" % (len(stats), label, depth, st.closest_rays, st.shadow_rays),
+                "flop_basis": "reference-equivalent: counted pairs x FLOP of the reference's test; see `executed_frac` of the triangle scans for what was executed",
+                "kernels": rows, "all_kinds": total, "dominant_by_time": max(rows, key=lambda k: rows[k]["ms"]) if rows else None})
+    rays = float(st.closest_rays + st.shadow_rays)
+    summary = {"what": "RT_FLAG_NO_FILTER on whole frames: every ray against every primitive, the mode BASELINE's largest configuration names",
+               "mrays_s": rays / elapsed / 1e6, "tests_per_s": total["pairs"] / elapsed, "tests_per_kernel_s": total["pairs_per_s"], "frac_of_fp32_peak": total["frac"],
+               "device_ms": st.device_ms, "rays": rays, "pairs": total["pairs"]}
+    return out, summary
 
 
 def brute_force_leg(abi, fi, cam, scene, depth, args, label):

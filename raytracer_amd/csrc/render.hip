@@ -1678,6 +1678,7 @@ DEV void brute_force_tile(const float4* lds, uint32_t first, uint32_t count, con
 // test as written.  The tile in LDS holds the pre-test records (stage_pretest_tile); the full-test record of a pair that
 // reaches the test as written is read from memory (one 64-byte line for the whole wave).
 // Counters (per wave, uniform): steps that reached the second stage and the test as written.
+// (Fetching the records of the next tile into registers while the current one is scanned was measured: no gain in either scan.)
 DEV void stage_pretest_tile(float4* lds, const float4* __restrict__ trif, uint32_t first, uint32_t count, bool shared, V3 o) {
     if (threadIdx.x >= count) return;
     const float4* g = trif + static_cast<size_t>(first + threadIdx.x) * 4;

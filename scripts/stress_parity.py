@@ -30,7 +30,8 @@ def run(first, count):
         cam = fi.camera()
         ref = scene.render(cam, fi.params(flags=abi.RT_FLAG_NO_FILTER), want_ids=True)
         for name, flags in (("default", 0), ("walk_all", abi.RT_FLAG_WALK_ALL), ("deep_walk", abi.RT_FLAG_WALK_ALL | abi.RT_FLAG_DEEP_WALK),
-                            ("brute force, test as written", abi.RT_FLAG_NO_FILTER | abi.RT_FLAG_PLAIN_TEST)):
+                            ("brute force, test as written", abi.RT_FLAG_NO_FILTER | abi.RT_FLAG_PLAIN_TEST),
+                            ("brute force, exact stages", abi.RT_FLAG_NO_FILTER | abi.RT_FLAG_EXACT_STAGES)):
             g = scene.render(cam, fi.params(flags=flags), want_ids=True)
             same = np.array_equal(g["ids"], ref["ids"]) and np.array_equal(g["rgb"], ref["rgb"]) and all(
                 getattr(g["stats"], f) == getattr(ref["stats"], f) for f in ("closest_rays", "hits", "shadow_rays", "shadow_blocked"))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 sqlite outputs of scripts/profile_r2.sh into the text summaries kept under profiles/.
+"""Turns the rocprofv3 sqlite outputs of scripts/profile_r3.sh into the text summaries kept under profiles/.
 
     python scripts/summarize_profile.py gpurun_out/prof_<tag> profiles/<name> [profiles/traffic.json]
 """
@@ -93,11 +93,16 @@ def main():
             if text.startswith('{"metric"'):
                 line = json.loads(text)
     if line and "roofline" in line and len(sys.argv) > 3:
-        label = line["config"]["workload"] + ("/brute-force-plain" if "false" in line["roofline"]["kernel"] else "/brute-force")
+        plain = "brute<1,0>" in str(line["roofline"].get("kernel"))
+        label = line["config"]["workload"] + ("/brute-force-plain" if plain else "/brute-force")
+        rows = line["roofline"].get("kernels", {})
         entry = {}
-        for tag, name, pairs in (("closest", "k_closest_tri_brute", line["roofline"]["pairs"]), ("shadow", "k_shadow_tri_brute", line["roofline"]["shadow_kernel"]["pairs"])):
-            cs = [v for k, v in merged.items() if name in k]
-            if not cs:
+        for tag, names, row, rays_per_lane in (("closest", ("k_closest_tri_brute",), "closest_triangle", 1 if plain else 2),
+                                               ("shadow", ("k_shadow_tri_pretest", "k_shadow_tri_brute"), "shadow_triangle", 1),
+                                               ("closest_ellipsoid", ("k_closest_ell_staged", "k_closest_ell<"), "closest_ellipsoid", 2)):
+            cs = [v for k, v in merged.items() if any(n in k for n in names)]
+            pairs = rows.get(row, {}).get("pairs")
+            if not cs or not pairs:
                 continue
             cs = cs[0]
             g = lambda c: cs[c][1] if c in cs else None
@@ -106,12 +111,20 @@ def main():
             if g("SQ_INSTS_VALU") and g("GRBM_GUI_ACTIVE"):
                 cycles = g("GRBM_GUI_ACTIVE") / 8.0 * (float(cs["SQ_INSTS_VALU"][0]) / cs["GRBM_GUI_ACTIVE"][0])
                 entry[tag + "_valu_issue_utilisation"] = 2.0 * g("SQ_INSTS_VALU") / (cycles * 1024.0)
-            if g("SQ_INSTS_VALU") and pairs:
-                entry[tag + "_valu_instructions_per_wave_and_triangle"] = g("SQ_INSTS_VALU") / (pairs / 64.0)
+            if g("SQ_INSTS_VALU"):
+                entry[tag + "_valu_instructions_per_pair_and_wave"] = g("SQ_INSTS_VALU") / (pairs / 64.0)
+        import datetime
+        import subprocess
+        try:
+            commit = subprocess.run(["git", "-C", os.path.dirname(os.path.abspath(__file__)), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        except OSError:
+            commit = ""
+        entry["source"] = "%s: rocprofv3 PMC passes of `bench.py` on this workload, run by the builder on %s%s" % (
+            os.path.basename(dst), datetime.date.today().isoformat(), (" at commit " + commit) if commit else "")
         table = json.load(open(sys.argv[3])) if os.path.exists(sys.argv[3]) else {}
         table[label] = entry
         json.dump(table, open(sys.argv[3], "w"), indent=1, sort_keys=True)
-        out.append("\n== brute-force triangle scans (%s) -> %s\n%s" % (label, sys.argv[3], json.dumps(entry, indent=1)))
+        out.append("\n== brute-force scans (%s) -> %s\n%s" % (label, sys.argv[3], json.dumps(entry, indent=1)))
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     with open(dst, "w") as f:
         f.write("\n".join(out) + "\n")

@@ -180,7 +180,8 @@ def test_many_lights_and_triangles_outside_the_staged_range(gpu, oracle, tmp_pat
     scene = gpu.Scene(fi.scene_desc)
     o = checkers.cpu_render(oracle, "rto_", fi.scene_desc, cam, fi.params(), want_ids=True)
     assert o["stats"].shadow_rays == 41 * o["stats"].hits and 0 < o["stats"].shadow_blocked < o["stats"].shadow_rays
-    modes = dict(MODES, brute_force=abi.RT_FLAG_NO_FILTER, brute_force_as_written=abi.RT_FLAG_NO_FILTER | abi.RT_FLAG_PLAIN_TEST)
+    modes = dict(MODES, brute_force=abi.RT_FLAG_NO_FILTER, brute_force_as_written=abi.RT_FLAG_NO_FILTER | abi.RT_FLAG_PLAIN_TEST,
+                 brute_force_exact_stages=abi.RT_FLAG_NO_FILTER | abi.RT_FLAG_EXACT_STAGES)
     for mode, flags in modes.items():
         g = scene.render(cam, fi.params(flags=flags), want_ids=True)
         assert np.array_equal(g["ids"], o["ids"]), mode

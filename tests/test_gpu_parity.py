@@ -120,7 +120,8 @@ def test_directional_light_that_is_not_of_unit_length(gpu, factor, name):
 def test_scene7_large_region_against_the_unmodified_reference(gpu):
     """A quarter of scene7's frame (the region with the model in it) against the reference itself: image and primary ids.
     The oracle, being scalar, is kept to a 32x16 crop above; the reference's AVX path on all host threads does 320x240 in seconds.
-    Also the plain form of the triangle test (RT_FLAG_PLAIN_TEST) on the same region in brute-force mode."""
+    Also the brute-force mode on the same region in its three forms: pre-tests first (the default), the test as written
+    (RT_FLAG_PLAIN_TEST) and the test in exact stages (RT_FLAG_EXACT_STAGES)."""
     if not checkers.have_ref():
         pytest.skip("oracle/_ref/librt_ref.so was not built (needs the reference sources)")
     from raytracer_amd import abi
@@ -131,11 +132,15 @@ def test_scene7_large_region_against_the_unmodified_reference(gpu):
     g = scene.render(cam, fi.params(**rect), want_ids=True)
     staged = scene.render(cam, fi.params(flags=abi.RT_FLAG_NO_FILTER, **rect), want_ids=True)
     plain = scene.render(cam, fi.params(flags=abi.RT_FLAG_NO_FILTER | abi.RT_FLAG_PLAIN_TEST, **rect), want_ids=True)
+    exact = scene.render(cam, fi.params(flags=abi.RT_FLAG_NO_FILTER | abi.RT_FLAG_EXACT_STAGES, **rect), want_ids=True)
     scene.close()
     r = checkers.cpu_render(checkers.load_ref(), "ref_", fi.scene_desc, cam, fi.params(**rect), want_ids=True)
     assert (g["ids"] < 0xFFFFFFFE).mean() > 0.2                      # the model covers a good part of the region
-    for other in (g, staged, plain):
+    for other in (g, staged, plain, exact):
         assert np.array_equal(other["ids"], r["ids"])
         assert np.array_equal(other["rgb"], r["rgb"])
     for f in ("closest_rays", "hits", "shadow_rays", "shadow_blocked"):
-        assert getattr(g["stats"], f) == getattr(staged["stats"], f) == getattr(plain["stats"], f), f
+        assert getattr(g["stats"], f) == getattr(staged["stats"], f) == getattr(plain["stats"], f) == getattr(exact["stats"], f), f
+    # the default form of the brute-force scan decides almost every pair before the test as written
+    steps = [list(v) for v in staged["stats"].brute_wave_steps]
+    assert steps[0][0] > 0 and steps[0][3] < 0.01 * steps[0][0] and steps[1][0] > steps[1][1] > steps[1][2] >= steps[1][3]
