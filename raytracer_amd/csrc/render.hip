@@ -3920,7 +3920,7 @@ constexpr int TRI_RAYS_PER_LANE = RT_TRI_RAYS_PER_LANE;
 #endif
 constexpr int PRETEST_RAYS_PER_LANE = RT_PRETEST_RAYS_PER_LANE;
 #ifndef RT_PRETEST_SHADOW_RAYS_PER_LANE
-#define RT_PRETEST_SHADOW_RAYS_PER_LANE 1
+#define RT_PRETEST_SHADOW_RAYS_PER_LANE 2
 #endif
 constexpr int PRETEST_SHADOW_RAYS_PER_LANE = RT_PRETEST_SHADOW_RAYS_PER_LANE;
 #ifndef RT_SORT_RAYS_MIN_TRIANGLES

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 for round in 1 2; do
 for v in "$@" librt_amd; do
-    RT_AMD_LIB=$PWD/raytracer_amd/lib/$v.so timeout -k 10 300 python bench.py --workload ${WL:-synthetic} --brute-crop ${CROP:-512x288} --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/tmp_bf.log 2>gpurun_out/tmp_bf.err || { tail -5 gpurun_out/tmp_bf.err; exit 1; }
+    RT_AMD_LIB=$PWD/raytracer_amd/lib/$v.so timeout -k 10 300 python bench.py --workload ${WL:-synthetic} --brute-crop ${CROP:-512x288} --steps 1 --warmup 0 --no-cpu-baseline --no-as-written > gpurun_out/tmp_bf.log 2>gpurun_out/tmp_bf.err || { tail -5 gpurun_out/tmp_bf.err; exit 1; }
     python3 - "$v" <<'PY'
 import json,sys
 d=json.loads(open('gpurun_out/tmp_bf.log').read().strip().splitlines()[-1])

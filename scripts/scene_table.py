@@ -44,5 +44,27 @@ def main():
             json.dump(table, f, indent=1)
 
 
+
+
+def markdown(path):
+    """The table of DESIGN.md from the JSON this script wrote."""
+    table = json.load(open(path))
+    print("| configuration | frame, default mode | Mrays/s | brute force: Mrays/s | tests/s (all kinds) | share of FP32 peak: all kinds; per scan | CPU reference (host threads) | Mrays/s | images identical (brute force = default; CPU = GPU) |")
+    print("|---|---|---|---|---|---|---|---|---|")
+    for label, line in table.items():
+        r, b, c = line["roofline"], line["brute_force"], line["cpu_baseline"]
+        short = {"closest_triangle": "tri", "closest_sphere": "sph", "closest_ellipsoid": "ell", "shadow_triangle": "tri↓", "shadow_sphere": "sph↓", "shadow_ellipsoid": "ell↓"}
+        kinds = ", ".join("%s %.0f" % (short[k], 100 * v["frac"]) for k, v in r["kernels"].items())
+        size = line["config"]["workload"].split("@")[1]
+        whole = c["sample"].startswith("centred %s-pixel" % size)
+        print("| %s | %.3f ms | %.0f | %.1f | %.3g | %.1f %%; %s | %.2f s, %s (%d) | %.3g | %s; %s |" % (
+            line["config"]["workload"], line["ms_per_step"], line["value"], b["mrays_s"], b["tests_per_s"], 100 * b["frac_of_fp32_peak"], kinds,
+            c["seconds"], "whole frame" if whole else c["sample"].split(" of")[0].replace("centred ", "").replace("-pixel crop", " crop"), c["threads_used"], c["value"],
+            "yes" if r["image_identical_to_default_mode"] else "NO", "yes" if c["image_identical_to_gpu"] else "NO"))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[1] == "--markdown":
+        markdown(sys.argv[2])
+    else:
+        main()
