@@ -151,7 +151,7 @@ typedef struct rt_stats {
                                        pairs walked ((pair_pretests - per-ray tests of the first level) / 16) is the fill of the lanes; for the
                                        depth-first walk a step serves either the lanes that hold a node or those that hold a leaf */
     uint64_t brute_wave_steps[2][4]; /* brute-force triangle scans in their default form, closest-hit / shadow: (wavefront, triangle) steps in all (64 lanes
-                                       x 2 rays per lane in the closest-hit scan, x 1 in the shadow scan), of which went past the sign test of the two dot
+                                       x 2 rays per lane), of which went past the sign test of the two dot
                                        products (rays of one origin skip that test), of which reached the second pre-test, of which reached the test as written */
 } rt_stats;
 

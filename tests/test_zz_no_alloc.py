@@ -1,6 +1,7 @@
 """rt_render_tiles_noalloc (the entry point that allocates nothing) against rt_render_tiles_device, through the C ABI:
 two calls in a row on one scene, the second with a smaller input; tile buffers must be identical byte for byte.
-Also: a share of more than RT_NOALLOC_MAX_TILES tiles is refused with a clear error."""
+Also: the device's free memory is the same after the call as before it, and a share of more than RT_NOALLOC_MAX_TILES tiles is
+refused with a clear error."""
 import numpy as np
 import pytest
 
@@ -17,7 +18,9 @@ def _both(gpu, scene, cam, prm):
     got = torch.full((n,), 9, dtype=torch.uint8, device="cuda:0")
     torch.cuda.synchronize()
     scene.render_tiles_device(cam, prm, want.data_ptr())
+    free_before = torch.cuda.mem_get_info(0)[0]              # hipMemGetInfo: free device memory
     gpu.render_tiles_noalloc(scene, cam, prm, got.data_ptr())
+    assert torch.cuda.mem_get_info(0)[0] == free_before      # the call took no device memory (and gave none back)
     torch.cuda.synchronize()
     return want.cpu().numpy(), got.cpu().numpy()
 
