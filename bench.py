@@ -393,7 +393,7 @@ def output_stage(api, scene, cam, prm, tiles, frame, fi, torch, world):
 KINDS = ("triangle", "sphere", "ellipsoid")
 CLOSEST_KERNELS = {False: ("k_closest_tri_brute<2,2>", "k_closest_sph_eye<2> (rays from the eye) / k_closest_sph<2>", "k_closest_ell_staged<2>"),
                    True: ("k_closest_tri_brute<1,0>", "k_closest_sph<2>", "k_closest_ell<2>")}
-SHADOW_KERNELS = {False: ("k_shadow_tri_pretest<2>", "k_shadow_brute<2,2>", "k_shadow_brute<2,1>"),
+SHADOW_KERNELS = {False: ("k_shadow_tri_pretest<2> (long launches) / <1>", "k_shadow_brute<2,2>", "k_shadow_brute<2,1>"),
                   True: ("k_shadow_tri_brute<0>", "k_shadow_sph<2>", "k_shadow_ell<2>")}
 # FLOP a lane executes per stage of the default form of the triangle scans (FMA = 2): the two dot products and a - o (13; d.n alone,
 # 5, for rays of one origin, whose other parts are per triangle), the first pre-test (17), the second (8), the test as written (68)
@@ -423,7 +423,7 @@ def kernel_table(st, fi, plain):
             total_ms += ms
             total_pairs += pairs
     # what the triangle scans executed (default form): lanes x FLOP of the stages their wavefronts went through
-    for scan, index, lanes in (("closest", 0, 128), ("shadow", 1, 128)):       # both scans take two rays per lane: 128 pairs per (wavefront, triangle) step
+    for scan, index, lanes in (("closest", 0, 64), ("shadow", 1, 64)):       # the library counts the steps in units of 64 pairs
         steps, stage1, stage2, exact = [float(v) for v in st.brute_wave_steps[index]]
         row = rows.get("%s_triangle" % scan)
         if row is None or steps == 0 or plain:

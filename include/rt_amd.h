@@ -150,8 +150,8 @@ typedef struct rt_stats {
     uint64_t walk_steps[2];         /* steps of up to 64 (ray, node) pairs, one pair per lane, below that level: 64 * walk_steps against the
                                        pairs walked ((pair_pretests - per-ray tests of the first level) / 16) is the fill of the lanes; for the
                                        depth-first walk a step serves either the lanes that hold a node or those that hold a leaf */
-    uint64_t brute_wave_steps[2][4]; /* brute-force triangle scans in their default form, closest-hit / shadow: (wavefront, triangle) steps in all (64 lanes
-                                       x 2 rays per lane), of which went past the sign test of the two dot
+    uint64_t brute_wave_steps[2][4]; /* brute-force triangle scans in their default form, closest-hit / shadow: (wavefront, triangle) steps in units of 64 pairs (a step of a
+                                       scan that takes two rays per lane counts twice) in all, of which went past the sign test of the two dot
                                        products (rays of one origin skip that test), of which reached the second pre-test, of which reached the test as written */
 } rt_stats;
 

@@ -1699,7 +1699,7 @@ struct BruteCounts { uint32_t steps = 0, stage1 = 0, stage2 = 0, exact = 0; };
 template <int R, bool SHARED, typename Visit>
 DEV void pretest_tile(const float4* lds, const float4* __restrict__ records, uint32_t first, uint32_t count, const V3 (&o)[R], const V3 (&d)[R],
                       const float (&o_max)[R], Mask everyone, BruteCounts& counts, Visit&& visit) {
-    counts.steps += count;
+    counts.steps += count * R;      // (the counters are in units of 64 pairs: a step of R rays per lane counts R times)
     // Every part of a record is read as one 16-byte read: left alone the compiler reads the words a stage needs with 12-byte and
     // strided reads, which occupy the LDS twice as long (the four SIMDs of a CU share it), so all four words are declared used.
 #define RT_WHOLE_WORD(v) asm volatile("" : : "v"((v).x), "v"((v).y), "v"((v).z), "v"((v).w))
@@ -1712,7 +1712,7 @@ DEV void pretest_tile(const float4* lds, const float4* __restrict__ records, uin
         bool kept[R];
         Mask keep = 0;
         if (SHARED) {      // (triangles behind the eye are rare: no sign test)
-            counts.stage1++;
+            counts.stage1 += R;
 #pragma unroll
             for (int r = 0; r < R; ++r) { kept[r] = pretest_stage1_shared(d[r], o_max[r], p0, p1, p2, pre[r]); keep |= ballot(kept[r]); }
         } else {
@@ -1722,21 +1722,21 @@ DEV void pretest_tile(const float4* lds, const float4* __restrict__ records, uin
 #pragma unroll
             for (int r = 0; r < R; ++r) { front[r] = pretest_front(o[r], d[r], p0, p1, behind[r]); ahead |= ballot(!behind[r]); }
             if ((ahead & everyone) == 0) continue;
-            counts.stage1++;
+            counts.stage1 += R;
             p2 = lds[2 * TILE_PRIMS + k];
             RT_WHOLE_WORD(p2);
 #pragma unroll
             for (int r = 0; r < R; ++r) { kept[r] = pretest_stage1_rest(front[r], d[r], o_max[r], p0, p1, p2, pre[r]) && !behind[r]; keep |= ballot(kept[r]); }
         }
         if ((keep & everyone) == 0) continue;
-        counts.stage2++;
+        counts.stage2 += R;
         const float4 p3 = lds[3 * TILE_PRIMS + k];
         RT_WHOLE_WORD(p3);
         keep = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) { kept[r] = kept[r] && pretest_stage2(pre[r], p3); keep |= ballot(kept[r]); }
         if ((keep & everyone) == 0) continue;
-        counts.exact++;
+        counts.exact += R;
         const float4* rec = records + static_cast<size_t>(first + k) * 4;
         const float4 t0 = rec[0], t1 = rec[1], t2 = rec[2];
         const float nn = rec[3].x;
@@ -4401,7 +4401,11 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                                 list = sb.list[b & 1u];
                             }
                             if (exact_stages) hipLaunchKernelGGL((k_shadow_tri_brute<1>), grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0, list);
-                            else hipLaunchKernelGGL(k_shadow_tri_pretest<PRETEST_SHADOW_RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0, list);
+                            // two rays per lane when the launch is long enough for every workgroup to refill its lanes many times over (ranges of 16
+                            // capacities); a short launch keeps one ray per lane, whose 256-ray workgroups fill and agree better (scene7 crop: 0.78 against 0.63)
+                            else if (PRETEST_SHADOW_RAYS_PER_LANE == 2 && static_cast<unsigned long long>(ray_blocks()) * n >= 16ull * SHADOW_MIN_RANGES)
+                                hipLaunchKernelGGL(k_shadow_tri_pretest<2>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0, list);
+                            else hipLaunchKernelGGL(k_shadow_tri_pretest<1>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0, list);
                         }
                         else if (prim == 1 && plain_test) hipLaunchKernelGGL(k_shadow_ell<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
                         else if (prim == 2 && plain_test) hipLaunchKernelGGL(k_shadow_sph<RAYS_PER_LANE>, grid, dim3(BLOCK), 0, stream, sc, sb, b, first_light, l0);
