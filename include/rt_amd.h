@@ -294,6 +294,9 @@ int rt_write_png_end(void);
  *   TRIANGLE, TRIANGLE_STAGED: a = a, a_to_b, a_to_c per item (9); b = origin, direction per item -> out[n]
  *                (distance or FLT_MAX; STAGED evaluates the staged form the brute-force scans use and reports
  *                NaN where that form declares itself unsure and the scans fall back to the plain form)
+ *   TRIANGLE_PRETEST: a, b as for TRIANGLE -> 3 floats per item: the result of the default form of the brute-force scans for the pair
+ *                (FLT_MAX where a step decided that the pair is a certain miss), the step that decided (0 sign test, 1 first pre-test,
+ *                2 second pre-test, 3 the test as written), and 1 / 0 for whether the form for rays of one origin keeps the pair up to the test as written
  *   SPHERE:      a = centre, radius per item (4); b = origin, direction per item -> out[n]
  *   ELLIPSOID, ELLIPSOID_STAGED: a = rows of the inverse transform, rows of the transform per item (24); b = origin, direction
  *                per item -> distance or FLT_MAX (closest-hit body, ray_tracing.cpp:555-579); STAGED evaluates the form the
@@ -322,6 +325,7 @@ int rt_write_png_end(void);
 #define RT_DEBUG_ELLIPSOID_SHADOW 12
 #define RT_DEBUG_ELLIPSOID_SHADOW_STAGED 13
 #define RT_DEBUG_ELLIPSOID_PARTS 14
+#define RT_DEBUG_TRIANGLE_PRETEST 15
 int rt_debug_eval(int op, uint32_t n, const float* a, const float* b, float* out);
 
 #ifdef __cplusplus

@@ -106,7 +106,7 @@ RT_FLAG_PLAIN_TEST = 8
 RT_FLAG_EXACT_STAGES = 16
 (RT_DEBUG_FP_POW, RT_DEBUG_FP_MIN, RT_DEBUG_FP_MAX, RT_DEBUG_DIVIDE, RT_DEBUG_DIVIDE_IN_RANGE, RT_DEBUG_PRIMARY_RAY,
  RT_DEBUG_SCENE_BOX, RT_DEBUG_TRIANGLE, RT_DEBUG_TRIANGLE_STAGED, RT_DEBUG_SPHERE, RT_DEBUG_ELLIPSOID, RT_DEBUG_ELLIPSOID_STAGED,
- RT_DEBUG_ELLIPSOID_SHADOW, RT_DEBUG_ELLIPSOID_SHADOW_STAGED, RT_DEBUG_ELLIPSOID_PARTS) = range(15)
+ RT_DEBUG_ELLIPSOID_SHADOW, RT_DEBUG_ELLIPSOID_SHADOW_STAGED, RT_DEBUG_ELLIPSOID_PARTS, RT_DEBUG_TRIANGLE_PRETEST) = range(16)
 RT_ID_MISS = 0xFFFFFFFF
 RT_ID_CULLED = 0xFFFFFFFE
 

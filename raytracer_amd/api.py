@@ -244,7 +244,7 @@ _DEBUG_SHAPES = {
     abi.RT_DEBUG_DIVIDE_IN_RANGE: (1, 0, 1, 1), abi.RT_DEBUG_PRIMARY_RAY: (0, 16, 4, 3), abi.RT_DEBUG_SCENE_BOX: (0, 6, 6, 2),
     abi.RT_DEBUG_TRIANGLE: (9, 0, 6, 1), abi.RT_DEBUG_TRIANGLE_STAGED: (9, 0, 6, 1), abi.RT_DEBUG_SPHERE: (4, 0, 6, 1),
     abi.RT_DEBUG_ELLIPSOID: (24, 0, 6, 1), abi.RT_DEBUG_ELLIPSOID_STAGED: (24, 0, 6, 2), abi.RT_DEBUG_ELLIPSOID_SHADOW: (16, 0, 6, 1),
-    abi.RT_DEBUG_ELLIPSOID_SHADOW_STAGED: (16, 0, 6, 2), abi.RT_DEBUG_ELLIPSOID_PARTS: (12, 0, 6, 8),
+    abi.RT_DEBUG_ELLIPSOID_SHADOW_STAGED: (16, 0, 6, 2), abi.RT_DEBUG_ELLIPSOID_PARTS: (12, 0, 6, 8), abi.RT_DEBUG_TRIANGLE_PRETEST: (9, 0, 6, 3),
 }
 
 

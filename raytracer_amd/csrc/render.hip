@@ -910,17 +910,11 @@ DEV void make_tri_record(V3 a, V3 ab, V3 ac, float4* o) {
     const bool regular = coord_max <= TAME_COORD && nn >= 8.673617379884035e-19f && nn <= 1.152921504606847e18f;   // 2^-60, 2^60
     o[3] = make_float4(nn, regular ? 1.0f / nn : __builtin_nanf(""), 0.0f, regular ? nn * (1.0f + BARY_BAND) : __builtin_nanf(""));
 }
-__global__ void __launch_bounds__(BLOCK) k_prep_triangles(const float* __restrict__ tri8, uint32_t nb, float4* __restrict__ out, float4* __restrict__ outf) {
-    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
-    if (k >= 8u * nb) return;
-    const uint32_t j = k / nb, i = k % nb;
-    const float* p = tri8 + static_cast<size_t>(i) * 72 + j;
-    const V3 a{p[0], p[8], p[16]}, ab{p[24], p[32], p[40]}, ac{p[48], p[56], p[64]};
-    float4* o = out + static_cast<size_t>(k) * 4;
-    make_tri_record(a, ab, ac, o);
-    const V3 n{o[0].w, o[1].w, o[2].w};
-    const float nn = o[3].x;
-    // pre-test record (pretest_stage1): nothing here has to match the reference's rounding
+// Pre-test record of one triangle (pretest_stage1 / pretest_stage2): (n, Ga) (a, Ha) (w1, 0) (w2, 0); `full` is its full-test record.
+// Nothing here has to match the reference's rounding.
+DEV void make_pretest_record(V3 a, V3 ab, V3 ac, const float4* full, float4* q) {
+    const V3 n{full[0].w, full[1].w, full[2].w};
+    const float nn = full[3].x;
     const float inv_nn = 1.0f / nn;
     const V3 w1 = scale(inv_nn, vcross(n, ab));
     const V3 w2 = scale(inv_nn, vcross(ac, n));
@@ -929,11 +923,20 @@ __global__ void __launch_bounds__(BLOCK) k_prep_triangles(const float* __restric
     const float a_max = fmaxf(fabsf(a.x), fmaxf(fabsf(a.y), fabsf(a.z)));
     const float G = 1.0001f * (1.0f / 32768.0f) * (n_max * e_max * inv_nn);
     const float H = 1.0001f * (G * a_max) + (1.0f / 4194304.0f);
-    float4* q = outf + static_cast<size_t>(k) * 4;
     q[0] = make_float4(n.x, n.y, n.z, 2.0f * G);
     q[1] = make_float4(a.x, a.y, a.z, 2.0f * H + 0.5f);
     q[2] = make_float4(w1.x, w1.y, w1.z, 0.0f);
     q[3] = make_float4(w2.x, w2.y, w2.z, 0.0f);
+}
+__global__ void __launch_bounds__(BLOCK) k_prep_triangles(const float* __restrict__ tri8, uint32_t nb, float4* __restrict__ out, float4* __restrict__ outf) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= 8u * nb) return;
+    const uint32_t j = k / nb, i = k % nb;
+    const float* p = tri8 + static_cast<size_t>(i) * 72 + j;
+    const V3 a{p[0], p[8], p[16]}, ab{p[24], p[32], p[40]}, ac{p[48], p[56], p[64]};
+    float4* o = out + static_cast<size_t>(k) * 4;
+    make_tri_record(a, ab, ac, o);
+    make_pretest_record(a, ab, ac, o, outf + static_cast<size_t>(k) * 4);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_reorder_pretest_records(const float4* __restrict__ trif, const uint32_t* __restrict__ k_of, uint32_t n, float4* __restrict__ out) {
@@ -3750,6 +3753,33 @@ __global__ void __launch_bounds__(BLOCK) k_debug_eval(int op, uint32_t n, const 
         if (store) out[j] = t;
         break;
     }
+    case RT_DEBUG_TRIANGLE_PRETEST: {   // a, b as for TRIANGLE; out: (result, the step that decided the pair) per item
+        // the default form of the brute-force scans for one pair: sign test, first and second pre-test, the test as written
+        float4 rec[4], pre[4];
+        const V3 ta{a[j * 9], a[j * 9 + 1], a[j * 9 + 2]}, tab{a[j * 9 + 3], a[j * 9 + 4], a[j * 9 + 5]}, tac{a[j * 9 + 6], a[j * 9 + 7], a[j * 9 + 8]};
+        make_tri_record(ta, tab, tac, rec);
+        make_pretest_record(ta, tab, tac, rec, pre);
+        const V3 o{b[j * 6], b[j * 6 + 1], b[j * 6 + 2]}, d{b[j * 6 + 3], b[j * 6 + 4], b[j * 6 + 5]};
+        const float o_max = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
+        float t = FLT_MAX, step = 0.0f;
+        bool behind;
+        Pre stage;
+        const PreFront front = pretest_front(o, d, pre[0], pre[1], behind);
+        if (!behind) {
+            step = 1.0f;
+            if (pretest_stage1_rest(front, d, o_max, pre[0], pre[1], pre[2], stage)) {
+                step = 2.0f;
+                if (pretest_stage2(stage, pre[3])) { step = 3.0f; t = hit_triangle(o, d, rec[0], rec[1], rec[2], rec[3].x); }
+            }
+        }
+        // rays of one origin: the record's a - o and (a - o).n, no sign test (stage_pretest_tile); must decide the same way from the first pre-test on
+        const V3 ao = sub(xyz(pre[1]), o);
+        Pre shared_stage;
+        const bool kept_shared = pretest_stage1_shared(d, o_max, make_float4(pre[0].x, pre[0].y, pre[0].z, vdot(ao, xyz(pre[0]))), make_float4(ao.x, ao.y, ao.z, pre[0].w),
+                                                       make_float4(pre[2].x, pre[2].y, pre[2].z, pre[1].w), shared_stage) && pretest_stage2(shared_stage, pre[3]);
+        if (store) { out[j * 3] = t; out[j * 3 + 1] = step; out[j * 3 + 2] = kept_shared ? 1.0f : 0.0f; }
+        break;
+    }
     case RT_DEBUG_SPHERE: {        // a: centre, radius per item (4); b: origin, direction per item
         const float t = hit_sphere(V3{b[j * 6], b[j * 6 + 1], b[j * 6 + 2]}, V3{b[j * 6 + 3], b[j * 6 + 4], b[j * 6 + 5]}, make_float4(a[j * 4], a[j * 4 + 1], a[j * 4 + 2], a[j * 4 + 3]));
         if (store) out[j] = t;
@@ -5128,7 +5158,7 @@ int rt_debug_eval(int op, uint32_t n, const float* a, const float* b, float* out
         {RT_DEBUG_DIVIDE_IN_RANGE, 1, 0, 1, 1}, {RT_DEBUG_PRIMARY_RAY, 0, 16, 4, 3}, {RT_DEBUG_SCENE_BOX, 0, 6, 6, 2},
         {RT_DEBUG_TRIANGLE, 9, 0, 6, 1}, {RT_DEBUG_TRIANGLE_STAGED, 9, 0, 6, 1}, {RT_DEBUG_SPHERE, 4, 0, 6, 1},
         {RT_DEBUG_ELLIPSOID, 24, 0, 6, 1}, {RT_DEBUG_ELLIPSOID_STAGED, 24, 0, 6, 2}, {RT_DEBUG_ELLIPSOID_SHADOW, 16, 0, 6, 1},
-        {RT_DEBUG_ELLIPSOID_SHADOW_STAGED, 16, 0, 6, 2}, {RT_DEBUG_ELLIPSOID_PARTS, 12, 0, 6, 8}};
+        {RT_DEBUG_ELLIPSOID_SHADOW_STAGED, 16, 0, 6, 2}, {RT_DEBUG_ELLIPSOID_PARTS, 12, 0, 6, 8}, {RT_DEBUG_TRIANGLE_PRETEST, 9, 0, 6, 3}};
     const auto* shape = &shapes[0];
     bool found = false;
     for (const auto& sh : shapes) if (sh.op == op) { shape = &sh; found = true; }

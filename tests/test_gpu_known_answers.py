@@ -265,3 +265,34 @@ def test_staged_ellipsoid_tests_equal_the_plain_ones(gpu, case):
     assert np.array_equal(staged_s[:, 0], plain_s)
     print("shadow: stage 0 %.3f, blocked %.3f" % ((staged_s[:, 1] == 0).mean(), plain_s.mean()))
     assert case == "out_of_range" or (0.02 < plain_s.mean() < 0.9 and (staged_s[:, 1] == 0).mean() > 0.05)
+
+
+@pytest.mark.parametrize("scale", [1.0, 30.0, 3000.0, 1e-3, 1e5])
+def test_pretest_form_of_the_triangle_test_equals_the_plain_one(gpu, scale):
+    """The default form of the brute-force scans (sign test, two conservative pre-tests, then the test as written) on the pairs of
+    test_staged_triangle_test_equals_the_plain_one: a step may call a pair decided only where the test as written returns no distance
+    (FLT_MAX, or NaN); where the form returns a distance it is the test's own.  Likewise the form for rays of one origin."""
+    rng = np.random.default_rng(int(scale * 1000) % 9973 + 1)
+    n = 1 << 21
+    tri, ray = _random_pairs(rng, n, scale)
+    k = n // 16
+    tri[:k, 3:6] = tri[:k, 6:9] * rng.uniform(0.5, 2.0, (k, 1)).astype(np.float32)       # degenerate: parallel edges
+    ray[k:2 * k, 3:] = tri[k:2 * k, 3:6] / np.linalg.norm(tri[k:2 * k, 3:6], axis=1, keepdims=True)   # rays in the triangle's plane direction
+    tri[2 * k:2 * k + 64] = 0.0                                                            # zero padding lanes
+    to_a = tri[3 * k:4 * k, 0:3] - ray[3 * k:4 * k, :3]                                   # rays through the vertex a
+    ray[3 * k:4 * k, 3:] = to_a / np.linalg.norm(to_a, axis=1, keepdims=True)
+    ray[4 * k:4 * k + 32, 3] = np.nan                                                      # a NaN and an infinity in a ray: never a hit either way
+    ray[4 * k + 32:4 * k + 64, 0] = np.inf
+    plain = gpu.debug_eval(abi.RT_DEBUG_TRIANGLE, tri, ray)
+    form = gpu.debug_eval(abi.RT_DEBUG_TRIANGLE_PRETEST, tri, ray).reshape(-1, 3)
+    hit = plain < FLT_MAX                                                                  # (false for NaN)
+    step = form[:, 1]
+    assert same_bits(form[step == 3, 0], plain[step == 3])                                 # the test as written ran: its result, bit for bit
+    assert (step[hit] == 3).all()                                                          # no hit was decided away ...
+    assert form[hit, 2].all()                                                              # ... by the form for rays of one origin either
+    assert (form[step < 3, 0] == FLT_MAX).all() and not hit[step < 3].any()
+    share = [float((step == q).mean()) for q in range(4)]
+    print("decided by: sign test %.3f, first pre-test %.3f, second %.3f, as written %.3f; hits %.3f" % (*share, hit.mean()))
+    if scale in (1.0, 30.0, 3000.0):
+        # the constructed pairs aim at the triangles: most reach the test as written; of those it rejects, the pre-tests must have taken a good part
+        assert share[0] > 0.02 and share[1] + share[2] > 0.1 and share[3] < hit.mean() + 0.12
