@@ -1,6 +1,6 @@
-"""A short run of the two random-scene campaigns (scripts/stress_parity.py, scripts/stress_oracle.py):
-every walk of the hierarchy against the brute-force mode, and the GPU path against the CPU oracle
-(and against the unmodified reference where its build is present), on bytes, ids and ray counters."""
+"""A short run of the random-scene campaigns (scripts/stress_parity.py, scripts/stress_long.py, scripts/stress_oracle.py):
+every walk of the hierarchy against the brute-force mode, the brute-force mode against the default mode on long ray lists, and
+the GPU path against the CPU oracle (and against the unmodified reference where its build is present), on bytes, ids and ray counters."""
 import os
 import sys
 
@@ -18,6 +18,12 @@ def test_walks_against_brute_force(gpu):
     """Seeds 700-739: 40 scenes, each in the default mode, both forced walks and the brute-force mode as written and in exact stages, against the brute-force mode."""
     import stress_parity
     assert stress_parity.run(700, 40) == 0, "seeds 700-739, see the MISMATCH lines above"
+
+
+def test_brute_force_against_default_on_long_ray_lists(gpu):
+    """Seeds 100-111: 12 scenes of 15-33 M samples and up to eight lights, the brute-force mode twice (and in exact stages) against the default mode."""
+    import stress_long
+    assert stress_long.run(100, 12) == 0, "seeds 100-111, see the MISMATCH lines above"
 
 
 def test_gpu_against_oracle(gpu):
