@@ -2744,7 +2744,8 @@ DEV ShadowRay make_shadow_ray(const State& st, uint32_t slot, bool point, V3 lv)
 // in the staging and the barriers, beside the other workgroups of their CU.  Neighbours in the list are neighbours in
 // the image, so the rays of a wave agree on most triangles and whole stages of the test are skipped; handing out rays
 // from one cursor per launch instead keeps every lane busy to the end but mixes rays from all over the image in a wave
-// (measured: 0.51 of the FP32 peak against 0.57 with ranges).
+// (measured: 0.51 of the FP32 peak against 0.57 with ranges; ranges of 2, 8 or 16 capacities handed out by a cursor, so that a workgroup
+// goes on to another range instead of trailing off with the long-lived rays of its own: 4426 / 4269 / 4209 ms per launch against 4177).
 #ifndef RT_SHADOW_COMPACT_TILES
 #define RT_SHADOW_COMPACT_TILES 4
 #endif
@@ -5483,6 +5484,7 @@ int rt_render_multi_end(int ticket, rt_stats* stats_per_device, double* exchange
         if (!frame.busy) return rt_fail(RT_ERR_ARGUMENT, "rt_render_multi_end: no frame under way with this ticket");
         frame.busy = false;
         Library& root = g_devices[0];
+        DeviceBinding bound(root);      // the events of the exchange are device 0's
         HIP_TRY(hipEventSynchronize(root.multi_exchange_end[ticket]));
         for (int d = 1; d < frame.n; ++d) HIP_TRY(hipEventSynchronize(g_devices[d].multi_sent[ticket]));
         if (exchange_ms) {
