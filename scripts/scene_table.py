@@ -47,7 +47,7 @@ def main():
 
 
 def markdown(path):
-    """The table of DESIGN.md from the JSON this script wrote."""
+    """A Markdown table (one row per configuration) from the JSON this script wrote."""
     table = json.load(open(path))
     print("| configuration | frame, default mode | Mrays/s | brute force: Mrays/s | tests/s (all kinds) | share of FP32 peak: all kinds; per scan | CPU reference (host threads) | Mrays/s | images identical (brute force = default; CPU = GPU) |")
     print("|---|---|---|---|---|---|---|---|---|")
