@@ -71,6 +71,13 @@ def main():
             if g("WRITE_SIZE") is not None:
                 n = cs["WRITE_SIZE"][0]
                 out.append("  derived: HBM-side write bytes per dispatch       %.3e  (WRITE_SIZE in KiB)" % (1024.0 * g("WRITE_SIZE") / n))
+            if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None and cs["FETCH_SIZE"][2] and cs["WRITE_SIZE"][2]:
+                # bytes over the kernel's own time in each pass (durations are in ns); the HBM3E peak is about 8000 GB/s
+                rate = 2.0 * 1024.0 * g("FETCH_SIZE") / cs["FETCH_SIZE"][2] + 1024.0 * g("WRITE_SIZE") / cs["WRITE_SIZE"][2]
+                out.append("  derived: HBM-side traffic                        %.1f GB/s = %.4f of 8000 GB/s" % (rate, rate / 8000.0))
+            if g("SQ_LDS_IDX_ACTIVE") is not None and g("GRBM_GUI_ACTIVE"):
+                # LDS_IDX_ACTIVE counts, per CU, the cycles its LDS is working on an instruction; 256 CUs; GUI_ACTIVE is summed over 8 XCDs
+                out.append("  derived: LDS busy = LDS_IDX_ACTIVE / (kernel cycles * 256 CUs) = %.3f" % (g("SQ_LDS_IDX_ACTIVE") / (g("GRBM_GUI_ACTIVE") / 8.0 * 256.0)))
             if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None:
                 out.append("  derived: L2 hit rate                             %.4f" % (g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))))
             if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
