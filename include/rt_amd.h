@@ -159,7 +159,9 @@ typedef struct rt_stats {
  * rt_render_tiles_begin / _end, rt_render_multi_begin / _end and rt_assemble_tiles_device take locks of the library, so
  * concurrent calls from any threads are safe and run one after the other (the reference's render_scanline is re-entrant;
  * parallelism here is inside a call).  Bounding records that have to be rebuilt for a camera far outside the scene are
- * rebuilt when no frame that reads them is in flight.  A frame begun and never ended is completed when the library is unloaded. */
+ * rebuilt when no frame that reads them is in flight.  A frame begun and never ended is completed when the library is unloaded.
+ * HIP's current device is a property of the thread: a calling thread need not have made the library's device current, every
+ * entry point that works on the device does so for the length of the call and puts the thread's device back as it found it. */
 typedef struct rt_scene rt_scene;          /* opaque: device-resident scene */
 typedef struct rt_file_info rt_file_info;  /* opaque: a parsed .test file */
 

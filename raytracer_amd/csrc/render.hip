@@ -4177,6 +4177,8 @@ int render_impl(const rt_scene* scene, const rt_camera_desc* cam, const rt_rende
                 uint32_t* ids_dev /* rect-shaped, nullable */, rt_stats* stats, bool no_alloc = false, int slot_index = 0) {
     Library& lib = current_device();
     if (!lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    DeviceBinding here(lib);      // a caller's thread that has never made this device current (HIP's current device is per thread)
+    if (!here.ok) return rt_fail(RT_ERR_DEVICE, "hipSetDevice failed");
     FrameSlot& slot = lib.slots[slot_index];
     std::lock_guard<std::mutex> one_at_a_time(slot.guard);
     if (!scene || !cam || !prm) return rt_fail(RT_ERR_ARGUMENT, "null argument");
@@ -4867,6 +4869,8 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out) {
         const int n_multi = g_multi_devices.load();
         if (n_multi <= 1) {
             Library& lib = current_device();
+            DeviceBinding here(lib);
+            if (!here.ok) return rt_fail(RT_ERR_DEVICE, "rt_scene_create: hipSetDevice failed");
             std::lock_guard<std::mutex> one_at_a_time(lib.guard);
             return scene_create_impl(desc, orders, out);
         }
@@ -5081,6 +5085,7 @@ int rt_render_tiles_end(int ticket, rt_stats* stats) {
 int rt_assemble_tiles_device(const void* gathered, uint32_t stride_tiles, const rt_render_params* params, void* rgb_dev) {
     Library& lib = current_device();
     if (!lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
+    DeviceBinding here(lib);
     std::lock_guard<std::mutex> one_at_a_time(lib.guard);
     if (!gathered || !params || !rgb_dev) return rt_fail(RT_ERR_ARGUMENT, "rt_assemble_tiles_device: null argument");
     const Rect rect = rect_of(*params);
@@ -5096,6 +5101,7 @@ int rt_render(const rt_scene* scene, const rt_camera_desc* camera, const rt_rend
     Library& lib = current_device();
     if (!lib.ready) return rt_fail(RT_ERR_DEVICE, "rt_init has not been called");
     if (!params || !rgb_out) return rt_fail(RT_ERR_ARGUMENT, "rt_render: null argument");
+    DeviceBinding here(lib);      // the buffers below belong to the device of this context, whatever the calling thread's HIP device was
     const Rect rect = rect_of(*params);
     const uint32_t world = params->tile_world ? params->tile_world : 1;
     const uint32_t my_tiles = rank_tiles(*params);
@@ -5166,6 +5172,7 @@ int rt_debug_eval(int op, uint32_t n, const float* a, const float* b, float* out
     if (!found) return rt_fail(RT_ERR_ARGUMENT, "rt_debug_eval: unknown operation");
     if (!a || !b || !out || n == 0 || n > (1u << 26)) return rt_fail(RT_ERR_ARGUMENT, "rt_debug_eval: null argument or item count out of range");
     const size_t na = static_cast<size_t>(shape->a_per_item) * n + shape->a_fixed, nb = static_cast<size_t>(shape->b_per_item) * n, no = static_cast<size_t>(shape->out_per_item) * n;
+    DeviceBinding here(lib);
     float* dev = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), (na + nb + no) * sizeof(float)));
     int rc = 0;
