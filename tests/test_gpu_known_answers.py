@@ -296,3 +296,51 @@ def test_pretest_form_of_the_triangle_test_equals_the_plain_one(gpu, scale):
     if scale in (1.0, 30.0, 3000.0):
         # the constructed pairs aim at the triangles: most reach the test as written; of those it rejects, the pre-tests must have taken a good part
         assert share[0] > 0.02 and share[1] + share[2] > 0.1 and share[3] < hit.mean() + 0.12
+
+
+def _pairs_near_edges(rng, n, scale):
+    """Rays whose crossing of the triangle's plane lies within 1e-8 .. 1e-2 (barycentric) of an edge or a vertex, on either side,
+    a third of them at grazing angles (1e-6 .. 1e-1 off the plane): where a conservative pre-test is most likely to err."""
+    e1 = rng.normal(size=(n, 3)) * rng.uniform(0.01, 1.0, (n, 1)) * scale
+    e2 = rng.normal(size=(n, 3)) * rng.uniform(0.01, 1.0, (n, 1)) * scale
+    a = rng.uniform(-scale, scale, (n, 3))
+    delta = 10.0 ** rng.uniform(-8.0, -2.0, n) * rng.choice([-1.0, 1.0], n)
+    along = rng.uniform(-0.1, 1.1, n)
+    which = rng.integers(0, 5, n)
+    u = np.where(which == 0, delta, np.where(which == 1, along, np.where(which == 2, along, np.where(which == 3, delta, 1.0 + delta))))
+    v = np.where(which == 0, along, np.where(which == 1, delta, np.where(which == 2, 1.0 - along + delta, np.where(which == 3, delta * rng.uniform(-1, 1, n), -delta))))
+    p = a + u[:, None] * e1 + v[:, None] * e2                       # the crossing: near edge u = 0, v = 0, u + v = 1, vertex a, vertex b
+    normal = np.cross(e1, e2)
+    normal /= np.maximum(np.linalg.norm(normal, axis=1, keepdims=True), 1e-30)
+    d = rng.normal(size=(n, 3))
+    grazing = rng.random(n) < 1.0 / 3.0
+    in_plane = e1 * rng.uniform(-1, 1, (n, 1)) + e2 * rng.uniform(-1, 1, (n, 1))
+    in_plane /= np.maximum(np.linalg.norm(in_plane, axis=1, keepdims=True), 1e-30)
+    tilt = 10.0 ** rng.uniform(-6.0, -1.0, (n, 1)) * rng.choice([-1.0, 1.0], (n, 1))
+    d = np.where(grazing[:, None], in_plane + tilt * normal, d)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t = 10.0 ** rng.uniform(-3.0, 1.0, (n, 1)) * scale
+    o = p - t * d
+    return np.concatenate([a, e1, e2], axis=1).astype(np.float32), np.concatenate([o, d], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("scale", [1.0, 30.0, 3000.0])
+def test_pretests_keep_every_hit_near_edges_and_at_grazing_angles(gpu, scale):
+    """4 M pairs per scale aimed at the edges and vertices of their triangles, a third of them grazing: the sign test and the two
+    conservative pre-tests (for rays with origins of their own and for rays of one origin) may decide a pair only where the test as
+    written returns no distance, and the staged form of the test returns the test's own bits or declares itself unsure."""
+    rng = np.random.default_rng(int(scale) + 77)
+    n = 1 << 22
+    tri, ray = _pairs_near_edges(rng, n, scale)
+    plain = gpu.debug_eval(abi.RT_DEBUG_TRIANGLE, tri, ray)
+    form = gpu.debug_eval(abi.RT_DEBUG_TRIANGLE_PRETEST, tri, ray).reshape(-1, 3)
+    staged = gpu.debug_eval(abi.RT_DEBUG_TRIANGLE_STAGED, tri, ray)
+    hit = plain < FLT_MAX
+    step = form[:, 1]
+    assert 0.2 < hit.mean() < 0.8                                   # the pairs straddle the edges
+    assert (step[hit] == 3).all() and form[hit, 2].all()
+    assert same_bits(form[step == 3, 0], plain[step == 3])
+    assert (form[step < 3, 0] == FLT_MAX).all()
+    unsure = np.isnan(staged) & ~np.isnan(plain)
+    assert same_bits(np.where(unsure, plain, staged), plain)
+    print("hits %.3f; decided before the test as written %.3f; staged form unsure %.4f" % (hit.mean(), (step < 3).mean(), unsure.mean()))
