@@ -350,7 +350,9 @@ def single_process_bench(args, api, abi, results_fd):
                       "primitives": {"triangles": int(fi.scene_desc.n_triangles), "spheres": int(fi.scene_desc.n_spheres), "ellipsoids": int(fi.scene_desc.n_ellipsoids)},
                       "lights": int(fi.scene_desc.n_point_lights) + int(fi.scene_desc.has_directional_light),
                       "mode": "bounding hierarchy + conservative pre-tests, exact test on the survivors",
-                      "exchange": "one process, rt_render_multi_begin / _end: RCCL grouped send/receive to device 0 and scatter into the image on the exchange streams, "
+                      "exchange": ("REHEARSAL, %d device contexts on ONE GPU (RT_AMD_DEVICES_ON_ONE_GPU): gather by device-to-device copies; not a multi-GPU measurement" % n)
+                                  if n > 1 and os.environ.get("RT_AMD_DEVICES_ON_ONE_GPU") else
+                                  "one process, rt_render_multi_begin / _end: RCCL grouped send/receive to device 0 and scatter into the image on the exchange streams, "
                                   "behind the next frame; image left in device memory" if n > 1 or os.environ.get("RT_AMD_COMM_ALWAYS") else "one device: no exchange, scatter into the image only"},
            "rays_per_step": rays / max(args.steps, 1), "per_device_ms": per_device_ms,
            "exchange_ms": sum(ms for _, ms in frames) / max(args.steps, 1),

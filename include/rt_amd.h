@@ -234,6 +234,8 @@ int rt_assemble_tiles_device(const void* gathered_tiles_dev, uint32_t tiles_per_
  *      (gather to device 0 + scatter into rgb_dev) is enqueued; end waits for that exchange and returns the per-device
  *      statistics (if begin was given want_stats) and the device time of the exchange.  Up to two frames may be under way,
  *      so that the tiles of frame k travel while frame k + 1 is traced: begin(k + 1); end(k); begin(k + 2); ...
+ *      (For tests on a machine with one GPU: with RT_AMD_DEVICES_ON_ONE_GPU set in the environment rt_init_devices(n) creates
+ *      its n device contexts on HIP device 0 and the gather is n device-to-device copies, RCCL taking one rank per GPU.)
  *  (2) ONE PROCESS PER GPU (rank r renders with tile_rank = r, tile_world = n): rank 0 calls rt_comm_unique_id and hands
  *      the identifier to the others by any means the host has; every rank calls rt_comm_init_rank after rt_init;
  *      after rt_render_tiles_device has returned, rt_comm_gather_tiles enqueues the exchange of the tile buffers on a

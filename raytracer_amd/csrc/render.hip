@@ -3883,7 +3883,8 @@ struct FrameSlot {
 };
 struct Library {
     bool ready = false;
-    int device = -1;
+    int device = -1;                        // this context's index (g_devices[device]); the HIP device of that number unless hip_device says otherwise
+    int hip_device = -1;                    // the HIP device the context lives on (rt_init_devices can put several contexts on one GPU: tests)
     FrameSlot slots[FRAME_SLOTS];
     hipStream_t stream = nullptr;           // = slots[0].lanes[0].stream: uploads, scene preparation, assembly
     unsigned char* scratch = nullptr;       // device address of `scratch` on this device (hipGetSymbolAddress)
@@ -3924,12 +3925,12 @@ struct DeviceBinding {
     bool ok;
     explicit DeviceBinding(Library& lib) : before(t_device) {
         if (hipGetDevice(&device_before) != hipSuccess) device_before = -1;
-        ok = hipSetDevice(lib.device) == hipSuccess;
+        ok = hipSetDevice(lib.hip_device) == hipSuccess;
         t_device = &lib;
     }
     ~DeviceBinding() {
         t_device = before;
-        const int back = before ? before->device : device_before;
+        const int back = before ? before->hip_device : device_before;
         if (back >= 0) (void)hipSetDevice(back);
     }
 };
@@ -4800,13 +4801,14 @@ int rt_device_count(void) {
 }
 
 // Creates the context of one device (streams, events, counters); idempotent.
-static int init_device(int device) {
+static int init_device(int device, int hip_device = -1) {
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
-    if (device < 0 || device >= n || device >= MAX_DEVICES) return rt_fail(RT_ERR_ARGUMENT, "rt_init: no such device");
+    if (hip_device < 0) hip_device = device;
+    if (device < 0 || hip_device >= n || device >= MAX_DEVICES) return rt_fail(RT_ERR_ARGUMENT, "rt_init: no such device");
     Library& lib = g_devices[device];
     if (lib.ready) return 0;
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipSetDevice(hip_device));
     for (FrameSlot& slot : lib.slots) {
         for (Lane& lane : slot.lanes) {
             HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
@@ -4832,6 +4834,7 @@ static int init_device(int device) {
     HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&lib.scratch), HIP_SYMBOL(scratch)));
     if (!lib.scratch) return rt_fail(RT_ERR_DEVICE, "rt_init: the scratch array has no device address");
     lib.device = device;
+    lib.hip_device = hip_device;
     lib.ready = true;
     Library* none = nullptr;
     g_first_device.compare_exchange_strong(none, &lib);
@@ -5342,6 +5345,7 @@ std::mutex g_multi_guard;   // one rt_render_multi_begin / _end at a time
 struct MultiFrame { bool busy = false; int n = 0; rt_stats stats[MAX_DEVICES]; bool timed = false; };
 MultiFrame g_multi_frames[2];
 int g_multi_next = 0;       // the buffer set the next frame takes
+bool g_copy_gather = false; // several contexts on one GPU (RT_AMD_DEVICES_ON_ONE_GPU): gather by device-to-device copies
 
 }  // namespace
 
@@ -5363,7 +5367,7 @@ int rt_comm_init_rank(const uint8_t id[RT_COMM_ID_BYTES], int rank, int world) {
     if (!id || world < 1 || rank < 0 || rank >= world) return rt_fail(RT_ERR_ARGUMENT, "rt_comm_init_rank: bad rank / world / identifier");
     if (lib.comm) return rt_fail(RT_ERR_ARGUMENT, "rt_comm_init_rank: this device already belongs to a communicator");
     if (int rc = load_rccl()) return rc;
-    HIP_TRY(hipSetDevice(lib.device));
+    HIP_TRY(hipSetDevice(lib.hip_device));
     ncclUniqueId uid;
     std::memcpy(uid.internal, id, RT_COMM_ID_BYTES);
     ncclComm_t comm = nullptr;
@@ -5405,9 +5409,14 @@ int rt_init_devices(int n_devices) {
     if (g_multi_devices.load() != 0) return rt_fail(RT_ERR_ARGUMENT, "rt_init_devices: already initialised with another number of devices");
     Library* first = g_first_device.load(std::memory_order_acquire);
     if (first && first->device != 0) return rt_fail(RT_ERR_ARGUMENT, "rt_init_devices: rt_init chose a device other than 0 before");
-    for (int d = 0; d < n_devices; ++d) if (int rc = init_device(d)) return rc;
+    // RT_AMD_DEVICES_ON_ONE_GPU in the environment (tests): every context lives on HIP device 0, so that the n-device host logic -
+    // replicas of the scene, one worker thread and one share of the tiles per context, rank-major gather, assembly - runs on a
+    // machine with one GPU.  RCCL refuses two ranks on one GPU: the gather is then n device-to-device copies.
+    const bool on_one_gpu = std::getenv("RT_AMD_DEVICES_ON_ONE_GPU") != nullptr;
+    for (int d = 0; d < n_devices; ++d) if (int rc = init_device(d, on_one_gpu ? 0 : d)) return rc;
     HIP_TRY(hipSetDevice(0));
-    if (n_devices > 1 || std::getenv("RT_AMD_COMM_ALWAYS")) {   // one device needs no exchange (the variable makes it go through RCCL all the same: tests)
+    g_copy_gather = on_one_gpu && n_devices > 1;
+    if (!g_copy_gather && (n_devices > 1 || std::getenv("RT_AMD_COMM_ALWAYS"))) {   // one device needs no exchange (the variable makes it go through RCCL all the same: tests)
         for (int d = 0; d < n_devices; ++d) if (g_devices[d].comm) return rt_fail(RT_ERR_ARGUMENT, "rt_init_devices: a device already belongs to a communicator");
         if (int rc = load_rccl()) return rc;
         ncclComm_t comms[MAX_DEVICES];
@@ -5467,6 +5476,10 @@ int rt_render_multi_begin(const rt_scene* scene, const rt_camera_desc* camera, c
             for (int d = 0; d < n; ++d) { devices[d] = &g_devices[d]; send[d] = g_devices[d].multi_tiles[set]; }
             if (int rc = enqueue_gather(devices, send, n, bytes, root.multi_gathered[set])) return rc;
             gathered = root.multi_gathered[set];
+        } else if (g_copy_gather) {
+            for (int d = 0; d < n; ++d)
+                if (bytes) HIP_TRY(hipMemcpyAsync(root.multi_gathered[set] + static_cast<size_t>(d) * bytes, g_devices[d].multi_tiles[set], bytes, hipMemcpyDeviceToDevice, root.comm_stream));
+            gathered = root.multi_gathered[set];
         }
         hipLaunchKernelGGL(k_assemble, dim3(ceil_div(rect.w * rect.h, BLOCK)), dim3(BLOCK), 0, root.comm_stream,
                            gathered, stride, static_cast<uint32_t>(n), rect.w, rect.h, rect.tiles_x, static_cast<uint8_t*>(rgb_dev));
@@ -5474,7 +5487,7 @@ int rt_render_multi_begin(const rt_scene* scene, const rt_camera_desc* camera, c
         HIP_TRY(hipEventRecord(root.multi_exchange_end[set], root.comm_stream));
         for (int d = 1; d < n; ++d) {      // the senders: their tile buffers may be written again once this has happened
             DeviceBinding other(g_devices[d]);
-            HIP_TRY(hipEventRecord(g_devices[d].multi_sent[set], g_devices[d].comm_stream));
+            HIP_TRY(hipEventRecord(g_devices[d].multi_sent[set], g_copy_gather ? root.comm_stream : g_devices[d].comm_stream));
         }
         frame.busy = true; frame.n = n; frame.timed = want_stats != 0;
         g_multi_next = 1 - set;

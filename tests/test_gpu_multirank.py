@@ -109,6 +109,58 @@ print("MULTI_OK")
 """
 
 
+SEVERAL_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+import torch
+from raytracer_amd import api
+n = %(n)d
+api.init_devices(n)
+fi = api.FileInfo(%(scene)r)
+scene = api.Scene(fi.scene_desc)                     # one replica per context
+cam = fi.camera()
+for rect in (dict(rect_x0=64, rect_y0=48, rect_w=300, rect_h=200), dict(rect_x0=0, rect_y0=0, rect_w=33, rect_h=17), dict()):
+    prm = fi.params(**rect)
+    single = scene.render(cam, prm)                   # the first context alone
+    multi = api.render_multi(scene, cam, prm, n)
+    assert np.array_equal(multi["rgb"], single["rgb"]) and multi["rgb"].any(), rect
+    for f in ("samples", "culled", "closest_rays", "hits", "shadow_rays", "shadow_blocked"):
+        assert sum(getattr(st, f) for st in multi["stats"]) == getattr(single["stats"], f), f
+    if rect.get("rect_w", 640) > 100:
+        assert all(st.closest_rays > 0 for st in multi["stats"])       # every context had a share
+# the image left on the device, two frames under way, different rectangles in turn
+prm_a, prm_b = fi.params(rect_x0=64, rect_y0=48, rect_w=300, rect_h=200), fi.params(rect_x0=10, rect_y0=300, rect_w=500, rect_h=100)
+want_a, want_b = scene.render(cam, prm_a)["rgb"], scene.render(cam, prm_b)["rgb"]
+bufs = [torch.zeros(max(want_a.size, want_b.size), dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+torch.cuda.synchronize()
+ticket = api.render_multi_begin(scene, cam, prm_a, bufs[0].data_ptr())
+for k in range(1, 7):
+    nxt = api.render_multi_begin(scene, cam, prm_b if k %% 2 else prm_a, bufs[k %% 2].data_ptr())
+    stats, ms = api.render_multi_end(ticket, n)
+    want = want_b if (k - 1) %% 2 else want_a
+    got = bufs[(k - 1) %% 2][:want.size].cpu().numpy().reshape(want.shape)
+    assert np.array_equal(got, want), k
+    assert sum(st.hits for st in stats) > 0
+    ticket = nxt
+api.render_multi_end(ticket, n)
+scene.close()
+print("SEVERAL_OK")
+"""
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_several_device_contexts_on_the_one_gpu(gpu, n):
+    """The n-device host logic of one process - a replica of the scene per context, a worker thread and a share of the tiles per
+    context, the rank-major gather and the assembly, two frames under way - with every context on the one GPU of the box
+    (RT_AMD_DEVICES_ON_ONE_GPU; the gather is then device-to-device copies, because RCCL refuses two ranks on one GPU).
+    Images equal the single-context render; the contexts' ray counters add up to its counters."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, RT_AMD_DEVICES_ON_ONE_GPU="1")
+    done = subprocess.run([sys.executable, "-c", SEVERAL_SCRIPT % {"root": ROOT, "scene": scene_path("scene6"), "n": n}], env=env, capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0 and "SEVERAL_OK" in done.stdout, done.stdout[-2000:] + done.stderr[-2000:]
+
+
 @pytest.mark.parametrize("through_rccl", [False, True])
 def test_single_process_multi_device_entry_point(gpu, through_rccl):
     """rt_init_devices + rt_render_multi in a process of their own (one device here: the partition, the per-device thread, the
