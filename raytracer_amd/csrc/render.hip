@@ -3,21 +3,23 @@
 //
 // One image is traced as a stream of ray batches instead of one recursive call per sample:
 //   k_primary        : camera rays + scene-box cull       (ray_tracing.cpp:460-473, :265-297, render_work_queue.cpp:37-49)
-//   k_closest_scan,
-//   k_closest_sph/ell: closest hit per primitive kind     (ray_tracing.cpp:484-608)
+//   k_closest_scan, k_closest_packet (box hierarchy), k_closest_tri_brute,
+//   k_closest_sph*, k_closest_ell* (every pair): closest hit per primitive kind (ray_tracing.cpp:484-608)
 //   k_hit            : kind choice, hit point, normal, ambient + emission (ray_tracing.cpp:610-686)
-//   k_shadow_scan,
-//   k_shadow_sph/ell : any-hit toward one light           (ray_tracing.cpp:347-458)
+//   k_shadow_scan, k_shadow_dfs (box hierarchy), k_shadow_tri_pretest, k_shadow_tri_brute,
+//   k_shadow_brute, k_shadow_sph/ell (every pair): any-hit toward one light (ray_tracing.cpp:347-458)
 //   k_shade          : Blinn-Phong per unblocked light, attenuation, reflection (ray_tracing.cpp:687-728)
 //   k_resolve        : 16-sample average and 8-bit conversion (render_work_queue.cpp:51-55)
 // Rays that are still alive are kept in index lists compacted in order (k_scan_flags,
 // k_scan_blocks, k_fill_list), so every launch runs with full wavefronts of rays that are
 // neighbours in the image.
 // Two ways through the primitive lists give the same bytes:
-//   brute force (RT_FLAG_NO_FILTER): every ray against every primitive through the literal
-//     test of the reference, records staged in LDS tiles and read as broadcasts;
-//   default: conservative bounds (axis-aligned boxes, slab test) over a three-level hierarchy
-//     of the primitives decide almost every pair; what is left goes through the same literal test.
+//   brute force (RT_FLAG_NO_FILTER): every ray against every primitive, records staged in LDS tiles and
+//     read as broadcasts; a pair is decided by a sign test or a conservative pre-test where that is
+//     certain and by the literal test of the reference otherwise (RT_FLAG_PLAIN_TEST: the literal test
+//     on every pair; RT_FLAG_EXACT_STAGES: the literal test cut into stages that are skipped per wave);
+//   default: conservative bounds (axis-aligned boxes, slab test) over a hierarchy of the primitives
+//     decide almost every pair; what is left goes through the same pre-tests and the same literal test.
 //     The closest hit is an atomicMin over (distance, scan index) keys, so the order of
 //     the visits does not matter.
 //
