@@ -22,8 +22,10 @@ def _fmt(a):
 
 def write_scene(path, n_triangles=1_000_000, n_ellipsoids=10_000, n_lights=8, width=3840, height=2160,
                 maxdepth=2, seed=1, extent=10.0, edge=0.15, materials_every=1000, ell_scale=(0.05, 0.3),
-                n_spheres=0, sphere_radius=(0.05, 0.3)):
-    """Writes the scene; returns the path.  Deterministic in its arguments."""
+                n_spheres=0, sphere_radius=(0.05, 0.3), directional=None, attenuation=(1.0, 0.0, 0.0)):
+    """Writes the scene; returns the path.  Deterministic in its arguments.
+    directional: None, or the direction (x, y, z) of a directional light of colour .1 (the parser normalises it);
+    attenuation: the three coefficients of the point lights' attenuation."""
     rng_t = np.random.Generator(np.random.PCG64(seed))
     rng_e = np.random.Generator(np.random.PCG64(seed + 1))
     rng_m = np.random.Generator(np.random.PCG64(seed + 2))
@@ -36,7 +38,9 @@ def write_scene(path, n_triangles=1_000_000, n_ellipsoids=10_000, n_lights=8, wi
     add("output synthetic.png")
     add("camera 0 0 %s 0 0 0 0 1 0 45" % ("%.6f" % (4.0 * extent)).rstrip("0").rstrip("."))
     add("ambient .05 .05 .05")
-    add("attenuation 1 0 0")
+    add("attenuation " + _fmt([attenuation])[0])
+    if directional is not None:
+        add("directional " + _fmt([directional])[0] + " .1 .1 .1")
     for i in range(n_lights):
         ang = 2.0 * math.pi * i / max(n_lights, 1)
         add("point %.6f %.6f %.6f .15 .15 .15" % (2.5 * extent * math.cos(ang), 0.8 * extent, 2.5 * extent * math.sin(ang)))

@@ -24,6 +24,11 @@ def run(first, count):
         kw = dict(n_triangles=int(rng.choice([2048, 5000, 20000, 40000])), n_ellipsoids=int(rng.choice([0, 100, 1000])), n_spheres=int(rng.choice([0, 0, 50])),
                   n_lights=int(rng.choice([1, 2, 5, 8])), width=w, height=h, maxdepth=int(rng.integers(1, 4)), seed=seed,
                   edge=float(rng.choice([0.15, 0.8, 2.0])))
+        more = np.random.default_rng(seed + 1_000_000)      # (a stream of its own: the parameters above stay what they were per seed)
+        if more.random() < 0.4:
+            kw["directional"] = tuple(float(v) for v in np.round(more.normal(size=3) + np.array([0.0, -1.0, 0.0]), 3))
+        if more.random() < 0.3:
+            kw["attenuation"] = (1.0, 0.05, 0.01)
         path = synth.ensure_scene_file(directory=d, **kw)
         fi = api.FileInfo(path)
         scene = api.Scene(fi.scene_desc)

@@ -32,6 +32,11 @@ def run(first, count, against_ref=False):
         kw["edge"] *= kw["extent"] / 10.0
         if kw["n_triangles"] + kw["n_ellipsoids"] + kw["n_spheres"] == 0:
             kw["n_triangles"] = 100
+        more = np.random.default_rng(seed + 1_000_000)      # (a stream of its own: the parameters above stay what they were per seed)
+        if more.random() < 0.4:
+            kw["directional"] = tuple(float(v) for v in np.round(more.normal(size=3) + np.array([0.0, -1.0, 0.0]), 3))
+        if more.random() < 0.3:
+            kw["attenuation"] = (1.0, 0.05, 0.01)
         if against_ref:
             # whole batches of 8 only: a zero-padding lane can be hit at any bounce (a sphere of radius 0 at the origin is
             # "hit" by a ray that passes within sqrt(eps) of its distance from it), and the reference then shades with

@@ -25,6 +25,11 @@ def run(first, count):
         kw["edge"] *= kw["extent"] / 10.0
         if kw["n_triangles"] + kw["n_ellipsoids"] + kw["n_spheres"] == 0:
             kw["n_spheres"] = 50
+        more = np.random.default_rng(seed + 1_000_000)      # (a stream of its own: the parameters above stay what they were per seed)
+        if more.random() < 0.4:
+            kw["directional"] = tuple(float(v) for v in np.round(more.normal(size=3) + np.array([0.0, -1.0, 0.0]), 3))
+        if more.random() < 0.3:
+            kw["attenuation"] = (1.0, 0.05, 0.01)
         fi = api.FileInfo(synth.ensure_scene_file(directory=d, **kw))
         scene = api.Scene(fi.scene_desc)
         cam = fi.camera()
