@@ -22,10 +22,11 @@ def _fmt(a):
 
 def write_scene(path, n_triangles=1_000_000, n_ellipsoids=10_000, n_lights=8, width=3840, height=2160,
                 maxdepth=2, seed=1, extent=10.0, edge=0.15, materials_every=1000, ell_scale=(0.05, 0.3),
-                n_spheres=0, sphere_radius=(0.05, 0.3), directional=None, attenuation=(1.0, 0.0, 0.0)):
+                n_spheres=0, sphere_radius=(0.05, 0.3), directional=None, attenuation=(1.0, 0.0, 0.0), eye=None, fov=45.0):
     """Writes the scene; returns the path.  Deterministic in its arguments.
     directional: None, or the direction (x, y, z) of a directional light of colour .1 (the parser normalises it);
-    attenuation: the three coefficients of the point lights' attenuation."""
+    attenuation: the three coefficients of the point lights' attenuation; eye: the camera position (default: outside the cloud, at
+    (0, 0, 4 extent)), looking at the centre; fov: its vertical field of view in degrees."""
     rng_t = np.random.Generator(np.random.PCG64(seed))
     rng_e = np.random.Generator(np.random.PCG64(seed + 1))
     rng_m = np.random.Generator(np.random.PCG64(seed + 2))
@@ -36,7 +37,10 @@ def write_scene(path, n_triangles=1_000_000, n_ellipsoids=10_000, n_lights=8, wi
     add("size %d %d" % (width, height))
     add("maxdepth %d" % maxdepth)
     add("output synthetic.png")
-    add("camera 0 0 %s 0 0 0 0 1 0 45" % ("%.6f" % (4.0 * extent)).rstrip("0").rstrip("."))
+    if eye is None and fov == 45.0:
+        add("camera 0 0 %s 0 0 0 0 1 0 45" % ("%.6f" % (4.0 * extent)).rstrip("0").rstrip("."))
+    else:
+        add("camera %s 0 0 0 0 1 0 %s" % (_fmt([eye if eye is not None else (0.0, 0.0, 4.0 * extent)])[0], _fmt([[fov]])[0]))
     add("ambient .05 .05 .05")
     add("attenuation " + _fmt([attenuation])[0])
     if directional is not None:

@@ -29,6 +29,10 @@ def run(first, count):
             kw["directional"] = tuple(float(v) for v in np.round(more.normal(size=3) + np.array([0.0, -1.0, 0.0]), 3))
         if more.random() < 0.3:
             kw["attenuation"] = (1.0, 0.05, 0.01)
+        if more.random() < 0.3:                              # an eye inside the cloud (rays start among the primitives), a wide or a narrow view
+            extent = kw.get("extent", 10.0)
+            kw["eye"] = tuple(float(v) for v in np.round(more.uniform(-0.8, 0.8, 3) * extent, 3))
+            kw["fov"] = float(more.choice([20.0, 70.0, 110.0]))
         path = synth.ensure_scene_file(directory=d, **kw)
         fi = api.FileInfo(path)
         scene = api.Scene(fi.scene_desc)
